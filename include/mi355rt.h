@@ -1,0 +1,186 @@
+/*
+ * mi355rt.h -- C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * The reference renderer has no FFI layer: its hot path is reached through the C++ class
+ * `Renderer` (reference renderer.h:21-50).  Each entry point below replaces the body of one
+ * `Renderer` member (or one call it makes into hittable/bvh/object code); the reference line it
+ * stands in for is cited on every declaration.  All arguments are plain pointers and sizes,
+ * caller-owned.  Every function returns RT_OK (0) or a negative rt_status; no exception crosses
+ * the boundary.  A context may be used from one host thread at a time (any thread); each call
+ * makes the context's device current.  The library never falls back to the CPU: without a usable
+ * HIP device rt_create fails.
+ */
+#ifndef MI355RT_H
+#define MI355RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_NBINS 30 /* reference spectrum.h:8, N_SAMPLE: 30 bins of 10 nm from 400 nm */
+
+typedef enum rt_status {
+	RT_OK = 0,
+	RT_ERR_INVALID = -1,    /* bad argument / call order */
+	RT_ERR_HIP = -2,        /* a HIP runtime call failed; text in rt_last_error */
+	RT_ERR_NO_DEVICE = -3,  /* no HIP device: there is no CPU fallback */
+	RT_ERR_NO_LIGHTS = -4,  /* Renderer::LoadMaterials returns false when no object is a light (renderer.cpp:41-42) */
+	RT_ERR_NO_MATERIAL = -5,/* Renderer::LoadMaterials returns false when an object has no material (renderer.cpp:29-32) */
+	RT_ERR_MESH = -6        /* malformed mesh (index out of range, face with < 3 corners, missing vn) */
+} rt_status;
+
+typedef struct rt_context rt_context;
+
+/* One ray, 32 bytes.  Origin and direction are widened to double on the device before the
+ * reference's fp64 triangle arithmetic, so a float ray means the same ray on both sides.
+ * tmax = +inf stands for the reference's numeric_limits<double>::max() (renderer.cpp:173). */
+typedef struct rt_ray {
+	float ox, oy, oz, tmin;
+	float dx, dy, dz, tmax;
+} rt_ray;
+
+#define RT_MISS 0xFFFFFFFFu
+
+/* Closest-hit result, 16 bytes.  prim = global face (polygon) index in obj order, i.e. the
+ * reference's rec.hit_object mapped through ObjModel::polygon_models[i][j] (object.cpp:131-133)
+ * as object_begin[i]+j; tri = fan-triangle index (triangle k of face f is tri_begin[f]+k);
+ * t = the reference's rec.t rounded once from double to float. */
+typedef struct rt_hit {
+	float t;
+	uint32_t prim;
+	uint32_t tri;
+	uint32_t object;
+} rt_hit;
+
+/* The reference `obj` container flattened (obj.h:10-31): what Renderer::Load hands to
+ * ObjModel::ObjModel (renderer.cpp:18-22, object.cpp:94-140).  Indices are 0-based; a corner's vt
+ * index is -1 when the face has no texture coordinate (obj.cpp:116-119); every corner needs a vn
+ * index (object.cpp:115 dereferences it). */
+typedef struct rt_mesh {
+	const double *v;  uint64_t n_v;   /* xyz triples, obj::v */
+	const double *vt; uint64_t n_vt;  /* uv0 triples, obj::vt (third component 0, obj.cpp:92) */
+	const double *vn; uint64_t n_vn;  /* xyz triples, obj::vn */
+	const int64_t *corners;           /* per corner: v, vt, vn index */
+	const uint64_t *face_begin;       /* n_faces+1 offsets into corners */
+	uint64_t n_faces;
+	const uint64_t *object_begin;     /* n_objects+1 offsets into faces, objobject::faces */
+	uint32_t n_objects;
+} rt_mesh;
+
+/* BSDF node wired to a NodeMaterial's Output (materialnode.cpp:1758-1795), constant-folded to
+ * 30-bin spectra by the host.  a/b: Lambertian a=albedo; DiffuseLight a=color; Dielectric a=n,
+ * b=surface_color; Conductor a=n, b=k; ColoredMetal a=albedo. */
+typedef enum rt_material_type {
+	RT_MAT_NONE = 0,          /* nothing wired to "BSDF": SampleBSDF false, BSDF/PDF/Emitted 0 */
+	RT_MAT_LAMBERTIAN = 1,    /* materialnode.cpp:262-295 */
+	RT_MAT_DIFFUSE_LIGHT = 2, /* materialnode.cpp:739-749 */
+	RT_MAT_DIELECTRIC = 3,    /* materialnode.cpp:354-419 */
+	RT_MAT_CONDUCTOR = 4,     /* materialnode.cpp:473-514 */
+	RT_MAT_COLORED_METAL = 5  /* materialnode.cpp:564-596 */
+} rt_material_type;
+
+typedef struct rt_material {
+	int32_t type;       /* rt_material_type */
+	int32_t light_flag; /* NodeMaterial::light_flag (materialnode.cpp:1613) */
+	double a[RT_NBINS];
+	double b[RT_NBINS];
+} rt_material;
+
+/* LensCamera state after SetLens + set_Camera (camera.h:101-209), copied field by field. */
+typedef struct rt_camera {
+	double film_sensitivity, aperture, film_width, film_height; /* camera.h:189-192 */
+	double n[RT_NBINS];                                          /* camera.h:193 lens refractive index */
+	double d;                                                    /* camera.h:117 sensor-lens distance */
+	double lens_maker_coefficient;                               /* camera.h:122 */
+	double origin[3], film_lower_left_corner[3], horizontal[3], vertical[3], w[3]; /* camera.h:137-144 */
+} rt_camera;
+
+typedef enum rt_algorithm { /* enum RenderingAlgorithm, renderer.h:12-18 */
+	RT_ALG_NAIVE = 0,  /* Renderer::NaivePathTracing, renderer.cpp:163-224 */
+	RT_ALG_NEE = 1,    /* Renderer::NEEPathTracingWithoutSpecular, renderer.cpp:227-325 */
+	RT_ALG_MIS = 2     /* Renderer::NEEMISPathTracing, renderer.cpp:329-475 */
+} rt_algorithm;
+
+typedef struct rt_stats {
+	uint64_t n_faces, n_triangles, n_objects, n_lights;
+	uint64_t bvh_nodes, bvh_depth, bvh_leaves;
+	double   bvh_build_seconds;
+	uint64_t closest_rays, any_rays, camera_samples; /* traced by render passes since rt_render_begin */
+	uint64_t device_bytes;                           /* geometry + BVH resident in HBM */
+} rt_stats;
+
+/* flat BVH2 node as built on the host, 64 bytes: two child boxes (float, rounded outward) and two
+ * child links.  link >= 0: interior node index; link < 0: leaf, c = ~link, first = c & 0x07FFFFFF
+ * (index into the leaf-ordered triangle arrays), count = (c >> 27) + 1. */
+typedef struct rt_bvh2_node {
+	float lo0[3], hi0[3], lo1[3], hi1[3];
+	int32_t child0, child1;
+	uint32_t pad[2];
+} rt_bvh2_node;
+
+/* ---- lifetime ---- */
+/* replaces: Renderer::Renderer (renderer.cpp:12-16).  device = HIP device ordinal. */
+int rt_create(int device, rt_context **out);
+void rt_destroy(rt_context *ctx);
+/* text of the last failure on this context (or of the last failed rt_create when ctx is NULL) */
+const char *rt_last_error(const rt_context *ctx);
+
+/* ---- scene ---- */
+/* replaces: ObjModel::ObjModel inside Renderer::Load (renderer.cpp:21, object.cpp:94-140) and the
+ * SAHBVHNode construction it triggers (bvh.cpp:134-232).  Builds per-polygon data exactly as the
+ * reference does (unit vertex normals, face normal with the flip rule, fan-triangle areas), builds
+ * a BVH on the host, flattens it and uploads nodes + triangles to HBM. */
+int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh);
+/* replaces: Renderer::LoadMaterials (renderer.cpp:24-44): one record per obj object, in object
+ * order; collects the light polygons; RT_ERR_NO_LIGHTS when there is none. */
+int rt_upload_materials(rt_context *ctx, const rt_material *per_object, uint32_t n_objects);
+/* replaces: reads of Renderer::cam inside RenderImage (renderer.cpp:91,113-114) */
+int rt_set_camera(rt_context *ctx, const rt_camera *cam);
+/* replaces: Renderer::Clear (renderer.cpp:47-51) plus dropping the uploaded scene */
+int rt_clear(rt_context *ctx);
+
+/* ---- closest hit / any hit ---- */
+/* replaces: world->Hit(r, t_min, t_max, rec) = ObjModel::Hit -> BVHNode::Hit (object.cpp:142-145,
+ * bvh.cpp:76-102) -> AABB::Hit (aabb.cpp:17-34) + ConvexPolygon::Hit (object.cpp:286-305).
+ * Host buffers; t64 (optional, may be NULL) receives rec.t in double, +inf on a miss.
+ * Ties in t between different polygons resolve to the lowest fan-triangle index. */
+int rt_trace_closest(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64);
+/* replaces: world->Occluded(r, t_min, t_max) (hittable.h:34-40, called at renderer.cpp:263). out[i] = 0/1 */
+int rt_trace_any(rt_context *ctx, const rt_ray *rays, uint64_t n, uint8_t *out);
+/* same, on buffers already resident in HBM, enqueued on `stream` (a hipStream_t, NULL = the
+ * context's own stream); no host synchronisation. d_t64 may be NULL. */
+int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream);
+int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_out, void *stream);
+
+/* ---- rendering ---- */
+/* replaces: the set-up of Renderer::RenderImage (renderer.cpp:56-58): sizes and clears the film
+ * (nx*ny*30 floats, element (i*ny+j)*30+bin, the reference's column-major pixel order).
+ * d_film: optional caller-owned device buffer of nx*ny*30 floats (e.g. memory an RCCL all-reduce
+ * will run on); NULL = the context allocates it. */
+int rt_render_begin(rt_context *ctx, int nx, int ny, int ns, int spectral_samples, int algorithm, uint64_t seed, void *d_film);
+/* replaces: passes s = first_sample .. first_sample+n_samples-1 of the loop at renderer.cpp:69-123
+ * (camera ray, integrator, film weight, Spectrum::add of rad/ns). Asynchronous on the context's stream. */
+int rt_render_pass(rt_context *ctx, int first_sample, int n_samples);
+int rt_render_sync(rt_context *ctx);
+/* replaces: reads of Renderer::spectrum_img (scene.cpp:929): nx*ny*30 doubles, same layout */
+int rt_download_film(rt_context *ctx, double *spectrum_img);
+/* replaces: the tonemap block renderer.cpp:124-143 for `samples_done` finished passes:
+ * rgb(spectrum*ns/samples_done), negative -> 0, pow 1/2.2, min 1; nx*ny*3 doubles */
+int rt_download_preview(rt_context *ctx, int samples_done, double *preview_img);
+int rt_film_device_ptr(rt_context *ctx, void **d_film, size_t *bytes);
+
+/* ---- introspection (tests, roofline accounting) ---- */
+int rt_get_stats(rt_context *ctx, rt_stats *out);
+/* copies the host-built BVH2: nodes (n_nodes records) and tri_index (leaf order -> fan triangle).
+ * Pass NULL pointers to query the counts only. */
+int rt_get_bvh2(rt_context *ctx, rt_bvh2_node *nodes, uint64_t *n_nodes, uint32_t *tri_index, uint64_t *n_tris);
+/* the context's stream as a hipStream_t, for callers that time with HIP events */
+void *rt_stream(rt_context *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

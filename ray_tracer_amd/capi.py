@@ -1,0 +1,231 @@
+"""ctypes bindings of include/mi355rt.h.  Loading fails loudly when the HIP library is missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+NBINS = 30
+MISS = 0xFFFFFFFF
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NO_LIGHTS, ERR_NO_MATERIAL, ERR_MESH = 0, -1, -2, -3, -4, -5, -6
+MAT_NONE, MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_COLORED_METAL = range(6)
+ALG_NAIVE, ALG_NEE, ALG_MIS = 0, 1, 2
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmi355rt.so")
+
+# every symbol include/mi355rt.h declares
+EXPORTS = [
+    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_upload_materials", "rt_set_camera", "rt_clear",
+    "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
+    "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
+    "rt_get_stats", "rt_get_bvh2", "rt_stream",
+]
+
+RAY_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("oz", "f4"), ("tmin", "f4"),
+                      ("dx", "f4"), ("dy", "f4"), ("dz", "f4"), ("tmax", "f4")])
+HIT_DTYPE = np.dtype([("t", "f4"), ("prim", "u4"), ("tri", "u4"), ("object", "u4")])
+BVH2_NODE_DTYPE = np.dtype([("lo0", "f4", 3), ("hi0", "f4", 3), ("lo1", "f4", 3), ("hi1", "f4", 3),
+                            ("child0", "i4"), ("child1", "i4"), ("pad", "u4", 2)])
+assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 16 and BVH2_NODE_DTYPE.itemsize == 64
+
+
+class Mesh(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("n_v", C.c_uint64), ("vt", C.c_void_p), ("n_vt", C.c_uint64),
+                ("vn", C.c_void_p), ("n_vn", C.c_uint64), ("corners", C.c_void_p), ("face_begin", C.c_void_p),
+                ("n_faces", C.c_uint64), ("object_begin", C.c_void_p), ("n_objects", C.c_uint32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("light_flag", C.c_int32), ("a", C.c_double * NBINS), ("b", C.c_double * NBINS)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("film_sensitivity", C.c_double), ("aperture", C.c_double), ("film_width", C.c_double),
+                ("film_height", C.c_double), ("n", C.c_double * NBINS), ("d", C.c_double),
+                ("lens_maker_coefficient", C.c_double), ("origin", C.c_double * 3),
+                ("film_lower_left_corner", C.c_double * 3), ("horizontal", C.c_double * 3),
+                ("vertical", C.c_double * 3), ("w", C.c_double * 3)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_faces", C.c_uint64), ("n_triangles", C.c_uint64), ("n_objects", C.c_uint64), ("n_lights", C.c_uint64),
+                ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64), ("bvh_leaves", C.c_uint64),
+                ("bvh_build_seconds", C.c_double), ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64),
+                ("camera_samples", C.c_uint64), ("device_bytes", C.c_uint64)]
+
+
+class BackendError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("mi355rt error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises when it has not been built (there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `make -C ray_tracer_amd/csrc` (hipcc, gfx950); "
+                          "this backend has no CPU path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    lib.rt_create.argtypes = [i32, C.POINTER(vp)]
+    lib.rt_destroy.argtypes = [vp]
+    lib.rt_destroy.restype = None
+    lib.rt_last_error.argtypes = [vp]
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_upload_mesh.argtypes = [vp, C.POINTER(Mesh)]
+    lib.rt_upload_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32]
+    lib.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    lib.rt_clear.argtypes = [vp]
+    lib.rt_trace_closest.argtypes = [vp, vp, u64, vp, vp]
+    lib.rt_trace_any.argtypes = [vp, vp, u64, vp]
+    lib.rt_trace_closest_device.argtypes = [vp, vp, u64, vp, vp, vp]
+    lib.rt_trace_any_device.argtypes = [vp, vp, u64, vp, vp]
+    lib.rt_render_begin.argtypes = [vp, i32, i32, i32, i32, i32, u64, vp]
+    lib.rt_render_pass.argtypes = [vp, i32, i32]
+    lib.rt_render_sync.argtypes = [vp]
+    lib.rt_download_film.argtypes = [vp, vp]
+    lib.rt_download_preview.argtypes = [vp, i32, vp]
+    lib.rt_film_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.rt_get_bvh2.argtypes = [vp, vp, C.POINTER(u64), vp, C.POINTER(u64)]
+    lib.rt_stream.argtypes = [vp]
+    lib.rt_stream.restype = vp
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One rt_context.  Methods raise BackendError on a non-zero status."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.rt_create(device, C.byref(h))
+        if rc != OK:
+            raise BackendError(rc, self.lib.rt_last_error(None).decode())
+        self.h = h
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise BackendError(rc, self.lib.rt_last_error(self.h).decode())
+
+    def upload_mesh(self, mesh):
+        """mesh: dict with v, vt, vn (float64 [n,3]), corners (int64 [nc,3]), face_begin, object_begin (uint64)."""
+        v = np.ascontiguousarray(mesh["v"], dtype=np.float64).reshape(-1, 3)
+        vt = np.ascontiguousarray(mesh["vt"], dtype=np.float64).reshape(-1, 3)
+        vn = np.ascontiguousarray(mesh["vn"], dtype=np.float64).reshape(-1, 3)
+        corners = np.ascontiguousarray(mesh["corners"], dtype=np.int64).reshape(-1, 3)
+        fb = np.ascontiguousarray(mesh["face_begin"], dtype=np.uint64)
+        ob = np.ascontiguousarray(mesh["object_begin"], dtype=np.uint64)
+        m = Mesh(_ptr(v), len(v), _ptr(vt), len(vt), _ptr(vn), len(vn), _ptr(corners), _ptr(fb), len(fb) - 1, _ptr(ob), len(ob) - 1)
+        self._check(self.lib.rt_upload_mesh(self.h, C.byref(m)))
+
+    def upload_materials(self, materials):
+        """materials: list of dicts {type, light_flag, a, b}, one per obj object."""
+        arr = (Material * max(len(materials), 1))()
+        for i, m in enumerate(materials):
+            arr[i].type = int(m["type"])
+            arr[i].light_flag = int(bool(m["light_flag"]))
+            for k in range(NBINS):
+                arr[i].a[k] = float(m["a"][k])
+                arr[i].b[k] = float(m["b"][k])
+        self._check(self.lib.rt_upload_materials(self.h, arr, len(materials)))
+
+    def set_camera(self, cam):
+        c = Camera()
+        for name in ("film_sensitivity", "aperture", "film_width", "film_height", "d", "lens_maker_coefficient"):
+            setattr(c, name, float(getattr(cam, name)))
+        for k in range(NBINS):
+            c.n[k] = float(cam.n[k])
+        for name in ("origin", "film_lower_left_corner", "horizontal", "vertical", "w"):
+            vec = getattr(cam, name)
+            for k in range(3):
+                getattr(c, name)[k] = float(vec[k])
+        self._check(self.lib.rt_set_camera(self.h, C.byref(c)))
+
+    def clear(self):
+        self._check(self.lib.rt_clear(self.h))
+
+    def trace_closest(self, rays, want_t64=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = len(rays)
+        hits = np.zeros(n, dtype=HIT_DTYPE)
+        t64 = np.zeros(n, dtype=np.float64) if want_t64 else None
+        self._check(self.lib.rt_trace_closest(self.h, _ptr(rays), n, _ptr(hits), _ptr(t64)))
+        return (hits, t64) if want_t64 else hits
+
+    def trace_any(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros(len(rays), dtype=np.uint8)
+        self._check(self.lib.rt_trace_any(self.h, _ptr(rays), len(rays), _ptr(out)))
+        return out
+
+    def trace_closest_device(self, d_rays, n, d_hits, d_t64=None, stream=None):
+        self._check(self.lib.rt_trace_closest_device(self.h, d_rays, n, d_hits, d_t64, stream))
+
+    def trace_any_device(self, d_rays, n, d_out, stream=None):
+        self._check(self.lib.rt_trace_any_device(self.h, d_rays, n, d_out, stream))
+
+    def render_begin(self, nx, ny, ns, spectral_samples, algorithm, seed=0, d_film=None):
+        self._dims = (nx, ny)
+        self._check(self.lib.rt_render_begin(self.h, nx, ny, ns, spectral_samples, algorithm, seed, d_film))
+
+    def render_pass(self, first_sample, n_samples):
+        self._check(self.lib.rt_render_pass(self.h, first_sample, n_samples))
+
+    def render_sync(self):
+        self._check(self.lib.rt_render_sync(self.h))
+
+    def download_film(self):
+        nx, ny = self._dims
+        out = np.zeros((nx * ny, NBINS), dtype=np.float64)
+        self._check(self.lib.rt_download_film(self.h, _ptr(out)))
+        return out
+
+    def download_preview(self, samples_done):
+        nx, ny = self._dims
+        out = np.zeros((nx * ny, 3), dtype=np.float64)
+        self._check(self.lib.rt_download_preview(self.h, samples_done, _ptr(out)))
+        return out
+
+    def film_device_ptr(self):
+        p, b = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.rt_film_device_ptr(self.h, C.byref(p), C.byref(b)))
+        return p.value, b.value
+
+    def stats(self):
+        s = Stats()
+        self._check(self.lib.rt_get_stats(self.h, C.byref(s)))
+        return {name: getattr(s, name) for name, _ in Stats._fields_}
+
+    def bvh2(self):
+        nn, nt = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.rt_get_bvh2(self.h, None, C.byref(nn), None, C.byref(nt)))
+        nodes = np.zeros(nn.value, dtype=BVH2_NODE_DTYPE)
+        tri_index = np.zeros(nt.value, dtype=np.uint32)
+        self._check(self.lib.rt_get_bvh2(self.h, _ptr(nodes), C.byref(nn), _ptr(tri_index), C.byref(nt)))
+        return nodes, tri_index
+
+    def stream(self):
+        return self.lib.rt_stream(self.h)

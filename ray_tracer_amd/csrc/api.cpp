@@ -1,0 +1,347 @@
+// extern "C" layer: argument checks, HIP error mapping, scene upload.  No kernels here.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+#include "context.h"
+#include "trace.h"
+
+using namespace mi355rt;
+
+namespace {
+thread_local std::string g_create_error;
+
+int set_err(rt_context *ctx, int code, const std::string &msg)
+{
+	if (ctx) ctx->error = msg;
+	else g_create_error = msg;
+	return code;
+}
+
+template <class T>
+bool dev_upload(rt_context *ctx, void *&dst, const std::vector<T> &src)
+{
+	size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+	if (ctx->fail_hip(hipMalloc(&dst, bytes), "hipMalloc")) return false;
+	ctx->device_bytes += bytes;
+	if (!src.empty() && ctx->fail_hip(hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D")) return false;
+	return true;
+}
+
+bool use_device(rt_context *ctx) { return !ctx->fail_hip(hipSetDevice(ctx->device), "hipSetDevice"); }
+
+bool ensure_stage(rt_context *ctx, uint64_t n)
+{
+	if (n <= ctx->stage_capacity) return true;
+	if (ctx->d_stage_rays) (void)hipFree(ctx->d_stage_rays);
+	if (ctx->d_stage_out) (void)hipFree(ctx->d_stage_out);
+	if (ctx->d_stage_t64) (void)hipFree(ctx->d_stage_t64);
+	ctx->d_stage_rays = ctx->d_stage_out = ctx->d_stage_t64 = nullptr;
+	ctx->stage_capacity = 0;
+	if (ctx->fail_hip(hipMalloc(&ctx->d_stage_rays, n * sizeof(rt_ray)), "hipMalloc rays")) return false;
+	if (ctx->fail_hip(hipMalloc(&ctx->d_stage_out, n * sizeof(rt_hit)), "hipMalloc hits")) return false;
+	if (ctx->fail_hip(hipMalloc(&ctx->d_stage_t64, n * sizeof(double)), "hipMalloc t64")) return false;
+	ctx->stage_capacity = n;
+	return true;
+}
+} // namespace
+
+bool rt_context::fail_hip(hipError_t e, const char *what)
+{
+	if (e == hipSuccess) return false;
+	error = std::string(what) + ": " + hipGetErrorString(e);
+	return true;
+}
+
+void rt_context::free_geometry()
+{
+	void **ptrs[] = {&d_nodes, &d_tri_a, &d_tri_b, &d_leaf_tri, &d_tri_face, &d_face_object};
+	for (void **p : ptrs) {
+		if (*p) (void)hipFree(*p);
+		*p = nullptr;
+	}
+	geom = DeviceGeom{};
+	device_bytes = 0;
+	has_mesh = false;
+}
+
+extern "C" {
+
+int rt_create(int device, rt_context **out)
+{
+	if (!out) return set_err(nullptr, RT_ERR_INVALID, "rt_create: out is NULL");
+	*out = nullptr;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0)
+		return set_err(nullptr, RT_ERR_NO_DEVICE, std::string("rt_create: no HIP device (") + hipGetErrorString(e) + "); this backend has no CPU path");
+	if (device < 0 || device >= count) return set_err(nullptr, RT_ERR_INVALID, "rt_create: device ordinal out of range");
+	rt_context *ctx = new (std::nothrow) rt_context();
+	if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "rt_create: out of host memory");
+	ctx->device = device;
+	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+		std::string msg = std::string("rt_create: ") + hipGetErrorString(e);
+		delete ctx;
+		return set_err(nullptr, RT_ERR_HIP, msg);
+	}
+	*out = ctx;
+	return RT_OK;
+}
+
+void rt_destroy(rt_context *ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	render_free(ctx->render);
+	ctx->free_geometry();
+	if (ctx->d_stage_rays) (void)hipFree(ctx->d_stage_rays);
+	if (ctx->d_stage_out) (void)hipFree(ctx->d_stage_out);
+	if (ctx->d_stage_t64) (void)hipFree(ctx->d_stage_t64);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
+{
+	if (!ctx || !mesh) return set_err(ctx, RT_ERR_INVALID, "rt_upload_mesh: NULL argument");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize")) return RT_ERR_HIP;
+	ctx->free_geometry();
+	ctx->has_materials = false;
+	std::string err;
+	if (!ctx->host.build(*mesh, err)) return set_err(ctx, RT_ERR_MESH, err);
+	BvhBuildOptions opt;
+	if (const char *s = std::getenv("MI355RT_MAX_LEAF")) opt.max_leaf = std::atoi(s);
+	build_bvh2(ctx->host, opt, ctx->bvh);
+	const HostScene &hs = ctx->host;
+	const uint64_t nt = hs.n_tris;
+	// leaf-ordered fp64 triangle records
+	std::vector<double> tri_a(6 * std::max<uint64_t>(nt, 1), 0.0), tri_b(6 * std::max<uint64_t>(nt, 1), 0.0);
+	std::vector<uint32_t> tri_leaf(nt);
+	for (uint64_t li = 0; li < nt; li++) {
+		const uint32_t t = ctx->bvh.tri_index[li];
+		tri_leaf[t] = (uint32_t)li;
+		const double *v0, *v1, *v2;
+		hs.tri_vertices(t, v0, v1, v2);
+		const double *fn = &hs.face_normal[3 * (size_t)hs.tri_face[t]];
+		double *a = &tri_a[6 * li], *b = &tri_b[6 * li];
+		a[0] = v0[0]; a[1] = v0[1]; a[2] = v0[2]; a[3] = fn[0]; a[4] = fn[1]; a[5] = fn[2];
+		b[0] = v1[0]; b[1] = v1[1]; b[2] = v1[2]; b[3] = v2[0]; b[4] = v2[1]; b[5] = v2[2];
+	}
+	if (!dev_upload(ctx, ctx->d_nodes, ctx->bvh.nodes) || !dev_upload(ctx, ctx->d_tri_a, tri_a) || !dev_upload(ctx, ctx->d_tri_b, tri_b) ||
+	    !dev_upload(ctx, ctx->d_leaf_tri, ctx->bvh.tri_index) || !dev_upload(ctx, ctx->d_tri_face, hs.tri_face) ||
+	    !dev_upload(ctx, ctx->d_face_object, hs.face_object)) {
+		std::string keep = ctx->error;
+		ctx->free_geometry();
+		return set_err(ctx, RT_ERR_HIP, keep);
+	}
+	ctx->geom.nodes = (const float4 *)ctx->d_nodes;
+	ctx->geom.tri_a = (const double2 *)ctx->d_tri_a;
+	ctx->geom.tri_b = (const double2 *)ctx->d_tri_b;
+	ctx->geom.leaf_tri = (const uint32_t *)ctx->d_leaf_tri;
+	ctx->geom.tri_face = (const uint32_t *)ctx->d_tri_face;
+	ctx->geom.face_object = (const uint32_t *)ctx->d_face_object;
+	ctx->geom.n_tris = (uint32_t)nt;
+	ctx->geom.depth = ctx->bvh.depth;
+	hipError_t e = render_upload_scene(ctx->render, hs, tri_leaf, ctx->geom.tri_face, ctx->geom.face_object, ctx->stream, err);
+	if (e != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
+	ctx->has_mesh = true;
+	return RT_OK;
+}
+
+int rt_upload_materials(rt_context *ctx, const rt_material *per_object, uint32_t n_objects)
+{
+	if (!ctx || !per_object) return set_err(ctx, RT_ERR_INVALID, "rt_upload_materials: NULL argument");
+	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_upload_materials: no mesh uploaded");
+	if (n_objects != ctx->host.n_objects) return set_err(ctx, RT_ERR_NO_MATERIAL, "rt_upload_materials: one record per obj object is required");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	for (uint32_t o = 0; o < n_objects; o++)
+		if (per_object[o].type < RT_MAT_NONE || per_object[o].type > RT_MAT_COLORED_METAL)
+			return set_err(ctx, RT_ERR_INVALID, "rt_upload_materials: unknown material type");
+	ctx->materials.assign(per_object, per_object + n_objects);
+	ctx->light_faces.clear();
+	for (uint32_t o = 0; o < n_objects; o++) // renderer.cpp:35-39
+		if (per_object[o].light_flag)
+			for (uint64_t f = ctx->host.object_begin[o]; f < ctx->host.object_begin[o + 1]; f++) ctx->light_faces.push_back((uint32_t)f);
+	ctx->has_materials = false;
+	if (ctx->light_faces.empty()) return set_err(ctx, RT_ERR_NO_LIGHTS, "rt_upload_materials: no object has light_flag set");
+	std::string err;
+	if (render_upload_materials(ctx->render, ctx->host, ctx->materials, ctx->light_faces, ctx->stream, err) != hipSuccess)
+		return set_err(ctx, RT_ERR_HIP, err);
+	ctx->has_materials = true;
+	return RT_OK;
+}
+
+int rt_set_camera(rt_context *ctx, const rt_camera *cam)
+{
+	if (!ctx || !cam) return set_err(ctx, RT_ERR_INVALID, "rt_set_camera: NULL argument");
+	ctx->camera = *cam;
+	ctx->has_camera = true;
+	return RT_OK;
+}
+
+int rt_clear(rt_context *ctx)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	(void)hipStreamSynchronize(ctx->stream);
+	ctx->free_geometry();
+	ctx->has_materials = false;
+	ctx->host = HostScene();
+	ctx->bvh = Bvh2();
+	return RT_OK;
+}
+
+int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream)
+{
+	if (!ctx || (n && (!d_rays || !d_hits))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_device: NULL argument");
+	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_device: no mesh uploaded");
+	if (n >= (1ull << 32) * 256ull) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_device: too many rays for one launch");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+	if (ctx->fail_hip(launch_trace_closest(ctx->geom, (const rt_ray *)d_rays, n, (rt_hit *)d_hits, (double *)d_t64, s), "closest-hit launch")) return RT_ERR_HIP;
+	return RT_OK;
+}
+
+int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_out, void *stream)
+{
+	if (!ctx || (n && (!d_rays || !d_out))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any_device: NULL argument");
+	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any_device: no mesh uploaded");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+	if (ctx->fail_hip(launch_trace_any(ctx->geom, (const rt_ray *)d_rays, n, (uint8_t *)d_out, s), "any-hit launch")) return RT_ERR_HIP;
+	return RT_OK;
+}
+
+int rt_trace_closest(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64)
+{
+	if (!ctx || (n && (!rays || !hits))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest: NULL argument");
+	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest: no mesh uploaded");
+	if (n == 0) return RT_OK;
+	if (!use_device(ctx) || !ensure_stage(ctx, n)) return RT_ERR_HIP;
+	if (ctx->fail_hip(hipMemcpyAsync(ctx->d_stage_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream), "H2D rays")) return RT_ERR_HIP;
+	int rc = rt_trace_closest_device(ctx, ctx->d_stage_rays, n, ctx->d_stage_out, t64 ? ctx->d_stage_t64 : nullptr, nullptr);
+	if (rc != RT_OK) return rc;
+	if (ctx->fail_hip(hipMemcpyAsync(hits, ctx->d_stage_out, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream), "D2H hits")) return RT_ERR_HIP;
+	if (t64 && ctx->fail_hip(hipMemcpyAsync(t64, ctx->d_stage_t64, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "D2H t64")) return RT_ERR_HIP;
+	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "closest-hit kernel")) return RT_ERR_HIP;
+	return RT_OK;
+}
+
+int rt_trace_any(rt_context *ctx, const rt_ray *rays, uint64_t n, uint8_t *out)
+{
+	if (!ctx || (n && (!rays || !out))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any: NULL argument");
+	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any: no mesh uploaded");
+	if (n == 0) return RT_OK;
+	if (!use_device(ctx) || !ensure_stage(ctx, n)) return RT_ERR_HIP;
+	if (ctx->fail_hip(hipMemcpyAsync(ctx->d_stage_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream), "H2D rays")) return RT_ERR_HIP;
+	int rc = rt_trace_any_device(ctx, ctx->d_stage_rays, n, ctx->d_stage_out, nullptr);
+	if (rc != RT_OK) return rc;
+	if (ctx->fail_hip(hipMemcpyAsync(out, ctx->d_stage_out, n, hipMemcpyDeviceToHost, ctx->stream), "D2H any")) return RT_ERR_HIP;
+	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "any-hit kernel")) return RT_ERR_HIP;
+	return RT_OK;
+}
+
+int rt_render_begin(rt_context *ctx, int nx, int ny, int ns, int spectral_samples, int algorithm, uint64_t seed, void *d_film)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	if (!ctx->has_mesh || !ctx->has_materials || !ctx->has_camera)
+		return set_err(ctx, RT_ERR_INVALID, "rt_render_begin: mesh, materials and camera must be set first");
+	if (nx <= 0 || ny <= 0 || ns <= 0 || spectral_samples <= 0 || spectral_samples > 65535)
+		return set_err(ctx, RT_ERR_INVALID, "rt_render_begin: nx, ny, ns must be positive and spectral_samples in 1..65535");
+	if (algorithm < RT_ALG_NAIVE || algorithm > RT_ALG_MIS)
+		return set_err(ctx, RT_ERR_INVALID, "rt_render_begin: algorithm must be Naive, NEE or MIS (the bidirectional integrators are not implemented)");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	std::string err;
+	hipError_t e = render_begin(ctx->render, ctx->camera, nx, ny, ns, spectral_samples, algorithm, seed, d_film, ctx->stream, err);
+	if (e != hipSuccess) return set_err(ctx, e == hipErrorInvalidValue ? RT_ERR_INVALID : RT_ERR_HIP, err);
+	return RT_OK;
+}
+
+int rt_render_pass(rt_context *ctx, int first_sample, int n_samples)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_render_pass: call rt_render_begin first");
+	if (first_sample < 0 || n_samples < 0) return set_err(ctx, RT_ERR_INVALID, "rt_render_pass: negative sample range");
+	if (n_samples == 0) return RT_OK;
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	std::string err;
+	if (render_pass(ctx->render, ctx->geom, first_sample, n_samples, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
+	return RT_OK;
+}
+
+int rt_render_sync(rt_context *ctx)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "render kernels")) return RT_ERR_HIP;
+	return RT_OK;
+}
+
+int rt_download_film(rt_context *ctx, double *spectrum_img)
+{
+	if (!ctx || !spectrum_img) return set_err(ctx, RT_ERR_INVALID, "rt_download_film: NULL argument");
+	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_download_film: nothing rendered");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	std::string err;
+	if (render_download_film(ctx->render, spectrum_img, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
+	return RT_OK;
+}
+
+int rt_download_preview(rt_context *ctx, int samples_done, double *preview_img)
+{
+	if (!ctx || !preview_img) return set_err(ctx, RT_ERR_INVALID, "rt_download_preview: NULL argument");
+	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_download_preview: nothing rendered");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	std::string err;
+	if (render_download_preview(ctx->render, samples_done, preview_img, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
+	return RT_OK;
+}
+
+int rt_film_device_ptr(rt_context *ctx, void **d_film, size_t *bytes)
+{
+	if (!ctx || !d_film) return RT_ERR_INVALID;
+	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_film_device_ptr: call rt_render_begin first");
+	*d_film = ctx->render.d_film;
+	if (bytes) *bytes = (size_t)ctx->render.nx * ctx->render.ny * RT_NBINS * sizeof(float);
+	return RT_OK;
+}
+
+int rt_get_stats(rt_context *ctx, rt_stats *out)
+{
+	if (!ctx || !out) return RT_ERR_INVALID;
+	std::memset(out, 0, sizeof(*out));
+	out->n_faces = ctx->host.n_faces;
+	out->n_triangles = ctx->host.n_tris;
+	out->n_objects = ctx->host.n_objects;
+	out->n_lights = ctx->light_faces.size();
+	out->bvh_nodes = ctx->bvh.nodes.size();
+	out->bvh_depth = ctx->bvh.depth;
+	out->bvh_leaves = ctx->bvh.n_leaves;
+	out->bvh_build_seconds = ctx->bvh.build_seconds;
+	out->closest_rays = ctx->render.closest_rays;
+	out->any_rays = ctx->render.any_rays;
+	out->camera_samples = ctx->render.camera_samples;
+	out->device_bytes = ctx->device_bytes;
+	return RT_OK;
+}
+
+int rt_get_bvh2(rt_context *ctx, rt_bvh2_node *nodes, uint64_t *n_nodes, uint32_t *tri_index, uint64_t *n_tris)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_get_bvh2: no mesh uploaded");
+	if (n_nodes) *n_nodes = ctx->bvh.nodes.size();
+	if (n_tris) *n_tris = ctx->bvh.tri_index.size();
+	if (nodes) std::memcpy(nodes, ctx->bvh.nodes.data(), ctx->bvh.nodes.size() * sizeof(rt_bvh2_node));
+	if (tri_index) std::memcpy(tri_index, ctx->bvh.tri_index.data(), ctx->bvh.tri_index.size() * sizeof(uint32_t));
+	return RT_OK;
+}
+
+void *rt_stream(rt_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+} // extern "C"

@@ -1,0 +1,265 @@
+#include "bvh_builder.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <limits>
+#include <thread>
+
+namespace mi355rt {
+namespace {
+
+struct Box {
+	float lo[3], hi[3];
+	void reset()
+	{
+		for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -std::numeric_limits<float>::infinity(); }
+	}
+	void grow(const Box &b)
+	{
+		for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); }
+	}
+	void grow_point(const float *p)
+	{
+		for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
+	}
+	float half_area() const
+	{
+		float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+		return dx * dy + dy * dz + dz * dx;
+	}
+};
+
+// largest float <= x / smallest float >= x: the device box test stays conservative
+inline float round_down(double x)
+{
+	float f = (float)x;
+	if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+	return f;
+}
+inline float round_up(double x)
+{
+	float f = (float)x;
+	if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+	return f;
+}
+
+struct TempNode {
+	Box box;
+	int32_t left = -1, right = -1; // temp node indices; leaf when left < 0
+	uint32_t first = 0, count = 0; // leaf: range in idx
+};
+
+struct Builder {
+	const BvhBuildOptions &opt;
+	std::vector<Box> prim_box;
+	std::vector<float> centroid; // 3 per prim
+	std::vector<uint32_t> idx;
+	std::vector<TempNode> temp;
+	std::atomic<uint32_t> next_node{0};
+	std::atomic<int> live_threads{1};
+	int max_threads = 1;
+
+	explicit Builder(const BvhBuildOptions &o) : opt(o) {}
+
+	uint32_t alloc_node() { return next_node.fetch_add(1); }
+
+	void make_leaf(uint32_t me, uint32_t begin, uint32_t end)
+	{
+		temp[me].left = temp[me].right = -1;
+		temp[me].first = begin;
+		temp[me].count = end - begin;
+	}
+
+	void build(uint32_t me, uint32_t begin, uint32_t end, int depth)
+	{
+		const uint32_t n = end - begin;
+		Box box, cbox;
+		box.reset();
+		cbox.reset();
+		for (uint32_t i = begin; i < end; i++) {
+			box.grow(prim_box[idx[i]]);
+			cbox.grow_point(&centroid[3 * (size_t)idx[i]]);
+		}
+		temp[me].box = box;
+		if (n == 1) { make_leaf(me, begin, end); return; }
+
+		uint32_t mid = 0;
+		bool split_found = false;
+		if (depth < opt.sah_depth_limit) {
+			const int B = opt.bins;
+			float best_cost = std::numeric_limits<float>::infinity();
+			int best_axis = -1, best_bin = -1;
+			std::vector<Box> bin_box(B), right_box(B);
+			std::vector<uint32_t> bin_cnt(B);
+			for (int axis = 0; axis < 3; axis++) {
+				float c0 = cbox.lo[axis], c1 = cbox.hi[axis];
+				if (!(c1 > c0)) continue;
+				float scale = (float)B / (c1 - c0);
+				for (int b = 0; b < B; b++) { bin_box[b].reset(); bin_cnt[b] = 0; }
+				for (uint32_t i = begin; i < end; i++) {
+					uint32_t p = idx[i];
+					int b = (int)((centroid[3 * (size_t)p + axis] - c0) * scale);
+					b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+					bin_box[b].grow(prim_box[p]);
+					bin_cnt[b]++;
+				}
+				Box acc;
+				acc.reset();
+				for (int b = B - 1; b > 0; b--) { acc.grow(bin_box[b]); right_box[b] = acc; }
+				acc.reset();
+				uint32_t nl = 0;
+				for (int b = 0; b < B - 1; b++) {
+					acc.grow(bin_box[b]);
+					nl += bin_cnt[b];
+					uint32_t nr = n - nl;
+					if (nl == 0 || nr == 0) continue;
+					float cost = acc.half_area() * (float)nl + right_box[b + 1].half_area() * (float)nr;
+					if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+				}
+			}
+			if (best_axis >= 0) {
+				float parent_area = box.half_area();
+				float split_cost = opt.cost_node + opt.cost_tri * best_cost / (parent_area > 0 ? parent_area : 1e-30f);
+				float leaf_cost = opt.cost_tri * (float)n;
+				if ((int)n <= opt.max_leaf && leaf_cost <= split_cost) { make_leaf(me, begin, end); return; }
+				float c0 = cbox.lo[best_axis], scale = (float)opt.bins / (cbox.hi[best_axis] - c0);
+				auto it = std::partition(idx.begin() + begin, idx.begin() + end, [&](uint32_t p) {
+					int b = (int)((centroid[3 * (size_t)p + best_axis] - c0) * scale);
+					b = b < 0 ? 0 : (b >= opt.bins ? opt.bins - 1 : b);
+					return b <= best_bin;
+				});
+				mid = (uint32_t)(it - idx.begin());
+				split_found = mid > begin && mid < end;
+			}
+		}
+		if (!split_found) {
+			if ((int)n <= opt.max_leaf) { make_leaf(me, begin, end); return; }
+			// all centroids coincide, or the SAH depth budget is spent: balanced split on the widest axis
+			int axis = 0;
+			float ext = -1.0f;
+			for (int a = 0; a < 3; a++) if (cbox.hi[a] - cbox.lo[a] > ext) { ext = cbox.hi[a] - cbox.lo[a]; axis = a; }
+			mid = begin + n / 2;
+			std::nth_element(idx.begin() + begin, idx.begin() + mid, idx.begin() + end, [&](uint32_t a, uint32_t b) {
+				float ca = centroid[3 * (size_t)a + axis], cb = centroid[3 * (size_t)b + axis];
+				return ca < cb || (ca == cb && a < b);
+			});
+		}
+		uint32_t l = alloc_node(), r = alloc_node();
+		temp[me].left = (int32_t)l;
+		temp[me].right = (int32_t)r;
+		bool spawn = n > 65536 && live_threads.load() < max_threads;
+		if (spawn) {
+			live_threads.fetch_add(1);
+			auto fut = std::async(std::launch::async, [this, l, begin, mid, depth] { build(l, begin, mid, depth + 1); });
+			build(r, mid, end, depth + 1);
+			fut.get();
+			live_threads.fetch_sub(1);
+		} else {
+			build(l, begin, mid, depth + 1);
+			build(r, mid, end, depth + 1);
+		}
+	}
+};
+
+struct Flattener {
+	const Builder &b;
+	Bvh2 &out;
+	// returns the link for temp node t; interior nodes are emitted in preorder
+	int32_t emit(int32_t t, uint32_t depth)
+	{
+		const TempNode &tn = b.temp[t];
+		if (tn.left < 0) {
+			uint32_t first = (uint32_t)out.tri_index.size();
+			for (uint32_t i = 0; i < tn.count; i++) out.tri_index.push_back(b.idx[tn.first + i]);
+			out.n_leaves++;
+			return make_leaf_link(first, tn.count);
+		}
+		if (depth + 1 > out.depth) out.depth = depth + 1;
+		uint32_t me = (uint32_t)out.nodes.size();
+		out.nodes.emplace_back();
+		const Box &b0 = b.temp[tn.left].box, &b1 = b.temp[tn.right].box;
+		int32_t c0 = emit(tn.left, depth + 1);
+		int32_t c1 = emit(tn.right, depth + 1);
+		rt_bvh2_node &n = out.nodes[me];
+		for (int a = 0; a < 3; a++) { n.lo0[a] = b0.lo[a]; n.hi0[a] = b0.hi[a]; n.lo1[a] = b1.lo[a]; n.hi1[a] = b1.hi[a]; }
+		n.child0 = c0;
+		n.child1 = c1;
+		n.pad[0] = n.pad[1] = 0;
+		return (int32_t)me;
+	}
+};
+
+} // namespace
+
+void build_bvh2(const HostScene &scene, const BvhBuildOptions &opt_in, Bvh2 &out)
+{
+	auto t_start = std::chrono::steady_clock::now();
+	BvhBuildOptions opt = opt_in;
+	opt.max_leaf = std::max(1, std::min(opt.max_leaf, 16));
+	opt.bins = std::max(4, std::min(opt.bins, 256));
+	out = Bvh2();
+	const uint64_t n = scene.n_tris;
+	const float inf = std::numeric_limits<float>::infinity();
+	auto empty_child = [&](rt_bvh2_node &nd, int which) {
+		float *lo = which ? nd.lo1 : nd.lo0, *hi = which ? nd.hi1 : nd.hi0;
+		for (int a = 0; a < 3; a++) { lo[a] = inf; hi[a] = -inf; }
+	};
+	if (n == 0) {
+		rt_bvh2_node root;
+		std::memset(&root, 0, sizeof(root));
+		empty_child(root, 0);
+		empty_child(root, 1);
+		root.child0 = root.child1 = make_leaf_link(0, 1);
+		out.nodes.push_back(root);
+		out.depth = 1;
+		return;
+	}
+	Builder b(opt);
+	b.prim_box.resize(n);
+	b.centroid.resize(3 * n);
+	b.idx.resize(n);
+	for (uint64_t t = 0; t < n; t++) {
+		const double *v0, *v1, *v2;
+		scene.tri_vertices(t, v0, v1, v2);
+		Box bx;
+		for (int a = 0; a < 3; a++) {
+			double mn = std::min(v0[a], std::min(v1[a], v2[a])), mx = std::max(v0[a], std::max(v1[a], v2[a]));
+			bx.lo[a] = round_down(mn);
+			bx.hi[a] = round_up(mx);
+			b.centroid[3 * t + a] = (float)(0.5 * (mn + mx));
+		}
+		b.prim_box[t] = bx;
+		b.idx[t] = (uint32_t)t;
+	}
+	b.temp.resize(2 * n);
+	int hw = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();
+	b.max_threads = std::max(1, std::min(hw, 32));
+	uint32_t root = b.alloc_node();
+	b.build(root, 0, (uint32_t)n, 0);
+
+	out.nodes.reserve(n);
+	out.tri_index.reserve(n);
+	Flattener fl{b, out};
+	if (b.temp[root].left < 0) {
+		// the whole scene fits one leaf: a root whose second child is an empty box
+		rt_bvh2_node nd;
+		std::memset(&nd, 0, sizeof(nd));
+		const Box &bx = b.temp[root].box;
+		for (int a = 0; a < 3; a++) { nd.lo0[a] = bx.lo[a]; nd.hi0[a] = bx.hi[a]; }
+		empty_child(nd, 1);
+		out.nodes.push_back(nd);
+		int32_t leaf = fl.emit((int32_t)root, 0);
+		out.nodes[0].child0 = leaf;
+		out.nodes[0].child1 = leaf;
+		out.depth = 1;
+	} else {
+		fl.emit((int32_t)root, 0);
+	}
+	out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+}
+
+} // namespace mi355rt

@@ -1,0 +1,40 @@
+// rt_context: owns one device's copy of the scene, the stream, and the render state.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "bvh_builder.h"
+#include "device_scene.h"
+#include "host_scene.h"
+#include "mi355rt.h"
+#include "render.h"
+
+struct rt_context {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	mutable std::string error;
+
+	mi355rt::HostScene host;
+	mi355rt::Bvh2 bvh;
+	bool has_mesh = false, has_materials = false, has_camera = false;
+
+	// geometry in HBM
+	void *d_nodes = nullptr, *d_tri_a = nullptr, *d_tri_b = nullptr, *d_leaf_tri = nullptr, *d_tri_face = nullptr,
+	     *d_face_object = nullptr;
+	mi355rt::DeviceGeom geom{};
+	uint64_t device_bytes = 0;
+
+	// staging for the host-buffer trace entry points (grown on demand)
+	void *d_stage_rays = nullptr, *d_stage_out = nullptr, *d_stage_t64 = nullptr;
+	uint64_t stage_capacity = 0;
+
+	std::vector<rt_material> materials;
+	std::vector<uint32_t> light_faces;
+	rt_camera camera{};
+
+	mi355rt::RenderState render;
+
+	bool fail_hip(hipError_t e, const char *what);
+	void free_geometry();
+};

@@ -1,0 +1,924 @@
+// Wavefront path tracer for gfx950: generate -> [extend -> shade -> connect-trace -> connect] per
+// bounce, over ray / path-state / connection queues resident in HBM.
+//
+// It restates Renderer::RenderImage and the three unidirectional integrators of the reference
+// (renderer.cpp:54-475) with the random draws taken in the reference's order from one counter-based
+// stream per (pixel, sample).  Shading arithmetic is fp32; hit distances come from the exact fp64
+// triangle test of trace.hip.  Each radiance term is added to the film the moment it is known
+// (emission in shade, direct light in connect), weighted by the sample's film factor, instead of
+// being summed per path and added at the end; a NaN term is dropped on its own where the reference
+// drops the whole sample (renderer.cpp:115).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "render.h"
+#include "trace.h"
+
+namespace mi355rt {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr float kPi = 3.14159265358979323846f;
+
+struct DevMaterial {
+	int type, light_flag;
+	float a[RT_NBINS], b[RT_NBINS];
+};
+
+// One wavelength band of the pass loop (renderer.cpp:85-88) with everything that depends on it
+// precomputed in fp64 on the host: Spectrum::add / integrate index ranges and edge weights
+// (spectrum.cpp:126-155), the bin Spectrum::get(central_wl) reads, and the thin-lens image distance.
+struct DevBand {
+	int min_i, max_i, get_bin, flags; // flags bit0: min_i >= 1, bit1: max_i <= N-2
+	float mod_min, mod_max, neg_a_over_d, a_positive;
+};
+
+struct DevCamera {
+	float origin[3], llc_rel[3], horizontal[3], vertical[3], w[3];
+	float half_aperture, weight_scale; // weight_scale = film_sensitivity / (d^2 p_image p_lens)
+};
+
+struct DeviceShade {
+	const float4 *tri_shade;        // 6 float4 per fan triangle: v0 v1 v2 n0 n1 n2 face_normal area2
+	const uint32_t *tri_face, *face_object, *face_tri_begin;
+	const float *face_area, *tri_cum;
+	const uint32_t *tri_leaf;       // fan triangle -> leaf-order index (exact polygon test in NEE)
+	const DevMaterial *materials;
+	const uint32_t *light_faces;
+	const DevBand *bands;
+	uint32_t n_lights, n_bands;
+};
+
+// 32 bytes per live path
+struct PathState {
+	uint64_t rng;
+	float beta, weight;
+	uint32_t pixel;
+	uint32_t band_bounce; // band | bounce << 16
+	uint32_t pad0, pad1;
+};
+
+// 32 bytes per connection ray (direct-light estimate waiting for its visibility query)
+struct ConnRec {
+	float c0, c1;
+	float nx, ny, nz;
+	uint32_t sel_face, pixel, band_kind; // band | kind << 16; kind 0: MIS light sample, 1: MIS bsdf sample, 2: NEE
+};
+
+struct Counters {
+	uint32_t n_next, n_conn, pad0, pad1;
+	unsigned long long closest_rays, any_rays;
+};
+
+struct Impl {
+	// shading data
+	float4 *tri_shade = nullptr;
+	uint32_t *face_tri_begin = nullptr, *tri_leaf = nullptr;
+	float *face_area = nullptr, *tri_cum = nullptr;
+	DevMaterial *materials = nullptr;
+	uint32_t *light_faces = nullptr;
+	DevBand *bands = nullptr;
+	uint32_t n_lights = 0, n_bands = 0;
+	const uint32_t *tri_face = nullptr, *face_object = nullptr;
+	DevCamera cam{};
+	// queues
+	uint64_t capacity = 0;
+	rt_ray *rays[2] = {nullptr, nullptr};
+	PathState *state[2] = {nullptr, nullptr};
+	rt_hit *hits = nullptr;
+	rt_ray *conn_rays = nullptr;
+	ConnRec *conn = nullptr;
+	rt_hit *conn_hits = nullptr;
+	uint8_t *conn_any = nullptr;
+	Counters *counters = nullptr;
+	Counters *h_counters = nullptr; // pinned
+	std::vector<float> film_host;
+};
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 F3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(float t, f3 a) { return F3(t * a.x, t * a.y, t * a.z); }
+__device__ __forceinline__ f3 neg(f3 a) { return F3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ float len(f3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ f3 unit(f3 a) { float l = len(a); return F3(a.x / l, a.y / l, a.z / l); }
+__device__ __forceinline__ f3 ld3(const float *p) { return F3(p[0], p[1], p[2]); }
+
+// the random stream shared with the CPU checker: splitmix64 steps from a per-(pixel, sample) seed
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t rng_seed(uint64_t seed, uint64_t pixel, uint64_t sample)
+{
+	return mix64(mix64(seed + 0x9E3779B97F4A7C15ULL * (sample + 1)) ^ (0xD1B54A32D192ED03ULL * (pixel + 1)));
+}
+__device__ __forceinline__ uint64_t rng_next(uint64_t &s)
+{
+	s += 0x9E3779B97F4A7C15ULL;
+	return mix64(s);
+}
+// top 24 bits: the truncation of the checker's 53-bit uniform, so threshold decisions agree
+__device__ __forceinline__ float rng_f32(uint64_t &s) { return (float)(rng_next(s) >> 40) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ uint32_t rng_below(uint64_t &s, uint32_t n) { return (uint32_t)((rng_next(s) >> 32) % n); }
+
+struct Onb { f3 u, v, w; };
+__device__ __forceinline__ Onb onb_from_w(f3 n) // onb.cpp:31-42
+{
+	Onb b;
+	b.w = unit(n);
+	f3 a = fabsf(b.w.x) > 0.9f ? F3(0, 1, 0) : F3(1, 0, 0);
+	b.v = unit(cross(b.w, a));
+	b.u = cross(b.w, b.v);
+	return b;
+}
+__device__ __forceinline__ f3 l2w(const Onb &b, f3 a) { return a.x * b.u + a.y * b.v + a.z * b.w; } // onb.cpp:21-24
+__device__ __forceinline__ f3 w2l(const Onb &b, f3 a) { return F3(dot(b.u, a), dot(b.v, a), dot(b.w, a)); } // onb.cpp:26-29
+
+__device__ __forceinline__ float spectrum_integrate(const float *data, const DevBand &bd) // spectrum.cpp:126-146
+{
+	float sum = 0.0f;
+	if (bd.flags & 1) sum += data[bd.min_i - 1] * bd.mod_min;
+	if (bd.flags & 2) sum += data[bd.max_i + 1] * bd.mod_max;
+	for (int i = bd.min_i; i <= bd.max_i; i++) sum += data[i] * 10.0f;
+	return sum;
+}
+
+__device__ __forceinline__ void film_add(float *film, uint32_t pixel, const DevBand &bd, float value) // spectrum.cpp:148-155
+{
+	if (isnan(value)) return; // renderer.cpp:115
+	for (int i = bd.min_i; i <= bd.max_i; i++) atomicAdd(&film[(size_t)pixel * RT_NBINS + i], value);
+}
+
+__device__ __forceinline__ float mat_emitted(const DevMaterial &m, const DevBand &bd) // materialnode.cpp:215-218,739-749
+{
+	return m.type == RT_MAT_DIFFUSE_LIGHT ? spectrum_integrate(m.a, bd) : 0.0f;
+}
+
+__device__ __forceinline__ bool mirror_pair(f3 vi, f3 vo) { return -vi.x == vo.x && -vi.y == vo.y && vi.z == vo.z; }
+
+__device__ __forceinline__ float mat_bsdf(const DevMaterial &m, f3 vi, f3 vo, int bin)
+{
+	switch (m.type) {
+	case RT_MAT_LAMBERTIAN: return vi.z < 0.0f ? 0.0f : m.a[bin] / kPi;                       // materialnode.cpp:278-288
+	case RT_MAT_CONDUCTOR:
+	case RT_MAT_COLORED_METAL: return mirror_pair(vi, vo) ? __int_as_float(0x7f800000) : 0.0f; // :503-508, :585-590
+	default: return 0.0f;
+	}
+}
+__device__ __forceinline__ float mat_pdf(const DevMaterial &m, f3 vi, f3 vo)
+{
+	switch (m.type) {
+	case RT_MAT_LAMBERTIAN: return vi.z < 0.0f ? 0.0f : vi.z / kPi;                            // :289-295
+	case RT_MAT_CONDUCTOR:
+	case RT_MAT_COLORED_METAL: return mirror_pair(vi, vo) ? __int_as_float(0x7f800000) : 0.0f; // :509-514, :591-596
+	default: return 0.0f;
+	}
+}
+
+__device__ __forceinline__ float rfresnel(float cos_theta, float n) // material.cpp:14-25
+{
+	const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+	const float sin_t = sin_theta / n;
+	if (sin_t > 1.0f) return 1.0f;
+	const float q = sqrtf(n * n - sin_theta * sin_theta);
+	const float rte = (cos_theta - q) / (cos_theta + q);
+	const float rtm = (n * n * cos_theta - q) / (n * n * cos_theta + q);
+	return (rte * rte + rtm * rtm) / 2.0f;
+}
+
+__device__ __forceinline__ float cfresnel(float cos_theta, float nre, float nim) // material.cpp:26-34
+{
+	const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+	const float sin_t = sin_theta / nre;
+	if (sin_t > 1.0f) return 1.0f;
+	// q = n*n - sin^2, s = principal sqrt(q)
+	float qre = nre * nre - nim * nim - sin_theta * sin_theta, qim = 2.0f * nre * nim;
+	float m = hypotf(qre, qim), sre, sim;
+	if (m == 0.0f) { sre = 0.0f; sim = 0.0f; }
+	else if (qre >= 0.0f) { sre = sqrtf(0.5f * (m + qre)); sim = qim / (2.0f * sre); }
+	else { float t = sqrtf(0.5f * (m - qre)); sre = fabsf(qim) / (2.0f * t); sim = qim < 0.0f ? -t : t; }
+	float are = cos_theta - sre, aim = -sim, bre = cos_theta + sre, bim = sim;
+	float den = bre * bre + bim * bim;
+	float fre = (are * bre + aim * bim) / den, fim = (aim * bre - are * bim) / den;
+	float r = hypotf(fre, fim);
+	return r * r;
+}
+
+// NodeMaterial::SampleBSDF for ImportanceType rays (materialnode.cpp:1758-1766 and the node bodies)
+__device__ __forceinline__ bool mat_sample(const DevMaterial &m, f3 normal, const Onb &uvw, f3 vo, int bin, uint64_t &rng,
+                                           f3 &vi, float &ratio, float &pdfval)
+{
+	switch (m.type) {
+	case RT_MAT_LAMBERTIAN: { // :262-276; CosinePdf builds its own frame from rec.normal (pdf.cpp:36-46,70-84)
+		Onb pb = onb_from_w(normal);
+		float r1 = rng_f32(rng), r2 = rng_f32(rng);
+		float phi = 2.0f * kPi * r1, st = sqrtf(r2), sphi, cphi;
+		sincosf(phi, &sphi, &cphi);
+		f3 gen = l2w(pb, F3(st * cphi, st * sphi, 1.0f - r2)); // z = 1 - r2 as in the reference
+		float cos_theta = dot(gen, pb.w);
+		pdfval = cos_theta >= 0.0f ? cos_theta / kPi : 0.0f;
+		vi = w2l(uvw, gen);
+		float bsdf = mat_bsdf(m, vi, vo, bin);
+		ratio = bsdf / pdfval;
+		return true;
+	}
+	case RT_MAT_DIELECTRIC: { // :354-407
+		float ref_idx = m.a[bin], surface_scale = m.b[bin];
+		float cos_o = vo.z, nz = 1.0f, n1, n2;
+		if (cos_o >= 0.0f) { n1 = 1.0f; n2 = ref_idx; }
+		else { nz = -1.0f; n1 = ref_idx; n2 = 1.0f; cos_o = fabsf(cos_o); }
+		float rel = n2 / n1;
+		float fresnel = rfresnel(cos_o, rel);
+		float r = rng_f32(rng);
+		pdfval = __int_as_float(0x7f800000);
+		if (r <= fresnel) {
+			vi = F3(-vo.x, -vo.y, vo.z);
+			ratio = surface_scale / cos_o;
+		} else {
+			float sin_o = sqrtf(1.0f - cos_o * cos_o), sin_t = sin_o / rel, cos_t = sqrtf(1.0f - sin_t * sin_t);
+			f3 h = unit(F3(vo.x, vo.y, 0.0f));
+			vi = F3(-sin_t * h.x, -sin_t * h.y, -cos_t * nz - sin_t * h.z);
+			ratio = surface_scale / (rel * rel * rel) / cos_t;
+		}
+		return true;
+	}
+	case RT_MAT_CONDUCTOR: { // :473-502
+		float nre = m.a[bin], kim = m.b[bin], cos_o = vo.z, rre, rim;
+		if (cos_o >= 0.0f) { rre = nre; rim = kim; } // n2/n1 with n1 = 1
+		else { float den = nre * nre + kim * kim; rre = nre / den; rim = -kim / den; cos_o = fabsf(cos_o); } // 1/(n+ik)
+		float fresnel = cfresnel(cos_o, rre, rim);
+		vi = F3(-vo.x, -vo.y, vo.z);
+		pdfval = __int_as_float(0x7f800000);
+		ratio = fresnel / cos_o;
+		return true;
+	}
+	case RT_MAT_COLORED_METAL: // :564-584
+		vi = F3(-vo.x, -vo.y, vo.z);
+		pdfval = __int_as_float(0x7f800000);
+		ratio = m.a[bin] / fabsf(vo.z);
+		return true;
+	default: return false; // base class, :203-206
+	}
+}
+
+__device__ __forceinline__ float power_heuristic2(float pdf1, float pdf2) // pdf.cpp:139-146 with beta = 2
+{
+	if (isinf(pdf1)) return 1.0f;
+	return pdf1 * pdf1 / (pdf1 * pdf1 + pdf2 * pdf2);
+}
+
+struct TriShade { f3 v0, v1, v2, n0, n1, n2, fn; float area2; };
+__device__ __forceinline__ TriShade load_tri(const float4 *tri_shade, uint32_t tri)
+{
+	const float4 s0 = tri_shade[6 * (size_t)tri], s1 = tri_shade[6 * (size_t)tri + 1], s2 = tri_shade[6 * (size_t)tri + 2];
+	const float4 s3 = tri_shade[6 * (size_t)tri + 3], s4 = tri_shade[6 * (size_t)tri + 4], s5 = tri_shade[6 * (size_t)tri + 5];
+	TriShade t;
+	t.v0 = F3(s0.x, s0.y, s0.z); t.v1 = F3(s0.w, s1.x, s1.y); t.v2 = F3(s1.z, s1.w, s2.x);
+	t.n0 = F3(s2.y, s2.z, s2.w); t.n1 = F3(s3.x, s3.y, s3.z); t.n2 = F3(s3.w, s4.x, s4.y);
+	t.fn = F3(s4.z, s4.w, s5.x); t.area2 = s5.y;
+	return t;
+}
+// rec.normal of HitTriangle (object.cpp:249-256): sub-triangle areas as weights, not renormalised
+__device__ __forceinline__ f3 shading_normal(const TriShade &t, f3 p)
+{
+	f3 r0 = cross(t.v1 - t.v0, p - t.v1), r1 = cross(t.v2 - t.v1, p - t.v2), r2 = cross(t.v0 - t.v2, p - t.v0);
+	f3 s = len(r1) * t.n0 + len(r2) * t.n1 + len(r0) * t.n2;
+	return F3(s.x / t.area2, s.y / t.area2, s.z / t.area2);
+}
+
+// wave-aggregated append: one atomic per wave, returns this lane's slot (or ~0u when !want)
+__device__ __forceinline__ uint32_t queue_append(uint32_t *counter, bool want)
+{
+	const unsigned long long mask = __ballot(want);
+	if (mask == 0) return 0xFFFFFFFFu;
+	const int lane = threadIdx.x & 63;
+	const int leader = __ffsll((long long)mask) - 1;
+	uint32_t base = 0;
+	if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+	base = __shfl(base, leader);
+	const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+	return want ? base + rank : 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generate: pixel jitter, band pick, thin-lens ray (renderer.cpp:81-94, camera.h:148-187)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBand *__restrict__ bands, uint32_t n_bands,
+                                                     int nx, int ny, int ns, int first_sample, uint64_t n_paths,
+                                                     uint64_t seed, float tmin, rt_ray *__restrict__ rays,
+                                                     PathState *__restrict__ state)
+{
+	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (idx >= n_paths) return;
+	const uint64_t npix = (uint64_t)nx * ny;
+	const uint32_t pixel = (uint32_t)(idx % npix);
+	const int sample = first_sample + (int)(idx / npix);
+	const int i = pixel / ny, j = pixel % ny;
+	uint64_t rng = rng_seed(seed, pixel, (uint64_t)sample);
+	const float u = ((float)i + rng_f32(rng)) / (float)nx;
+	const float v = ((float)j + rng_f32(rng)) / (float)ny;
+	const uint32_t k = rng_below(rng, n_bands);
+	const DevBand bd = bands[k];
+	float l0, l1;
+	do {
+		l0 = 2.0f * rng_f32(rng) - 1.0f;
+		l1 = 2.0f * rng_f32(rng) - 1.0f;
+	} while (sqrtf(l0 * l0 + l1 * l1) > 1.0f);
+	const f3 hor = ld3(cam.horizontal), ver = ld3(cam.vertical);
+	const f3 isp = ld3(cam.llc_rel) + u * hor + v * ver;              // image_sensor_pos - origin
+	const f3 lens = (l0 * cam.half_aperture) * hor + (l1 * cam.half_aperture) * ver; // random_point_on_lens - origin
+	const float cos_theta = dot(unit(lens - isp), neg(ld3(cam.w)));
+	f3 dir = unit(bd.neg_a_over_d * isp - lens);                      // target - random_point_on_lens
+	if (bd.a_positive == 0.0f) dir = neg(dir);
+	const f3 org = ld3(cam.origin) + lens;
+	rt_ray r;
+	r.ox = org.x; r.oy = org.y; r.oz = org.z; r.tmin = tmin;
+	r.dx = dir.x; r.dy = dir.y; r.dz = dir.z; r.tmax = __int_as_float(0x7f800000);
+	rays[idx] = r;
+	PathState st;
+	st.rng = rng;
+	st.beta = 1.0f;
+	const float c2 = cos_theta * cos_theta;
+	st.weight = cam.weight_scale * c2 * c2 / (float)ns; // renderer.cpp:113-116
+	st.pixel = pixel;
+	st.band_bounce = k;
+	st.pad0 = st.pad1 = 0;
+	state[idx] = st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade: one path vertex.  Emission, light pick and light point, BSDF samples, Russian roulette in
+// the reference's order; appends connection rays and the continuation ray.
+// ---------------------------------------------------------------------------------------------
+template <int ALG>
+__global__ void __launch_bounds__(kBlock) k_shade(DeviceShade sh, uint32_t n, const rt_ray *__restrict__ rays,
+                                                  const PathState *__restrict__ state, const rt_hit *__restrict__ hits,
+                                                  rt_ray *__restrict__ next_rays, PathState *__restrict__ next_state,
+                                                  rt_ray *__restrict__ conn_rays, ConnRec *__restrict__ conn,
+                                                  Counters *__restrict__ counters, float *__restrict__ film)
+{
+	const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+	const bool live = idx < n;
+	bool survive = false, want_c0 = false, want_c1 = false;
+	rt_ray nr{}, cr0{}, cr1{};
+	ConnRec c0{}, c1{};
+	PathState st{};
+	if (live) {
+		st = state[idx];
+		const rt_hit h = hits[idx];
+		if (h.prim != RT_MISS) {
+			const rt_ray r = rays[idx];
+			const uint32_t band = st.band_bounce & 0xFFFFu, bounce = st.band_bounce >> 16;
+			const DevBand bd = sh.bands[band];
+			const f3 o = F3(r.ox, r.oy, r.oz), d = F3(r.dx, r.dy, r.dz);
+			const f3 p = o + h.t * d;
+			const TriShade tri = load_tri(sh.tri_shade, h.tri);
+			const f3 nrm = shading_normal(tri, p);
+			const DevMaterial &m = sh.materials[h.object];
+			const float tmin = r.tmin;
+			bool alive = true;
+			if (ALG == RT_ALG_NAIVE) {
+				film_add(film, st.pixel, bd, st.beta * mat_emitted(m, bd) * st.weight); // renderer.cpp:197
+			} else if (m.light_flag) { // renderer.cpp:242-251 / 346-355
+				if (bounce != 0) alive = false;
+				else film_add(film, st.pixel, bd, mat_emitted(m, bd) * st.weight);
+			}
+			if (alive) {
+				const Onb uvw = onb_from_w(nrm);
+				const f3 vo = w2l(uvw, neg(d));
+				if (ALG != RT_ALG_NAIVE) {
+					const uint32_t sel = rng_below(st.rng, sh.n_lights);
+					const uint32_t lf = sh.light_faces[sel];
+					// GetRandomPointOnPolygon (object.cpp:340-372)
+					const float rr = rng_f32(st.rng);
+					const uint32_t t0 = sh.face_tri_begin[lf], nt = sh.face_tri_begin[lf + 1] - t0;
+					uint32_t lt = t0 + nt - 1;
+					for (uint32_t ti = 0; ti < nt; ti++)
+						if (rr < sh.tri_cum[t0 + ti]) { lt = t0 + ti; break; }
+					const TriShade ltri = load_tri(sh.tri_shade, lt);
+					float x = rng_f32(st.rng), y = rng_f32(st.rng);
+					if (x + y >= 1.0f) { x = 1.0f - x; y = 1.0f - y; }
+					const f3 pl = ltri.v0 + x * (ltri.v1 - ltri.v0) + y * (ltri.v2 - ltri.v0);
+					const float area = sh.face_area[lf];
+					const f3 to_l = pl - p;
+					const float dist = len(to_l);
+					const f3 sd = F3(to_l.x / dist, to_l.y / dist, to_l.z / dist);
+					const f3 vi = w2l(uvw, sd);
+					const float bsdf = mat_bsdf(m, vi, vo, bd.get_bin);
+					const float lpa = 1.0f / area / (float)sh.n_lights;
+					cr0.ox = p.x; cr0.oy = p.y; cr0.oz = p.z; cr0.tmin = tmin;
+					cr0.dx = sd.x; cr0.dy = sd.y; cr0.dz = sd.z;
+					c0.nx = nrm.x; c0.ny = nrm.y; c0.nz = nrm.z;
+					c0.sel_face = lf;
+					c0.pixel = st.pixel;
+					if (ALG == RT_ALG_NEE) { // renderer.cpp:258-286
+						cr0.tmax = dist - 0.0001f;
+						const float G = fabsf(dot(sd, ltri.fn) * dot(sd, nrm) / dot(to_l, to_l));
+						const float light = mat_emitted(sh.materials[sh.face_object[lf]], bd);
+						c0.c0 = bsdf * st.beta * light * G / lpa * st.weight;
+						c0.c1 = dist;
+						c0.band_kind = band | (2u << 16);
+						want_c0 = c0.c0 != 0.0f; // a zero term needs no visibility query
+					} else { // renderer.cpp:361-401
+						cr0.tmax = dist + 0.001f;
+						const float spdf = mat_pdf(m, vi, vo);
+						c0.c0 = st.beta * bsdf / lpa * st.weight;
+						c0.c1 = spdf / fabsf(dot(sd, nrm));
+						c0.band_kind = band | (0u << 16);
+						want_c0 = c0.c0 != 0.0f;
+						// BSDF-sampled direct light, renderer.cpp:404-433
+						f3 gvi;
+						float ratio, pdfv;
+						if (mat_sample(m, nrm, uvw, vo, bd.get_bin, st.rng, gvi, ratio, pdfv)) {
+							const f3 sdir = l2w(uvw, gvi); // not normalised, :413
+							cr1.ox = p.x; cr1.oy = p.y; cr1.oz = p.z; cr1.tmin = 0.001f;
+							cr1.dx = sdir.x; cr1.dy = sdir.y; cr1.dz = sdir.z; cr1.tmax = __int_as_float(0x7f800000);
+							c1 = c0;
+							c1.c0 = st.beta * ratio * fabsf(gvi.z) * st.weight;
+							c1.c1 = pdfv / fabsf(gvi.z);
+							c1.band_kind = band | (1u << 16);
+							want_c1 = true;
+						}
+					}
+				}
+				// continuation sample (renderer.cpp:199-208 / 290-300 / 440-450)
+				f3 gvi;
+				float ratio, pdfv;
+				const bool respawn = mat_sample(m, nrm, uvw, vo, bd.get_bin, st.rng, gvi, ratio, pdfv);
+				if (ALG == RT_ALG_NAIVE) {
+					if (respawn) {
+						st.beta *= ratio * fabsf(gvi.z);
+						if (!(rng_f32(st.rng) < 0.5f)) { // :211-215
+							st.beta /= 0.5f;
+							const f3 nd = l2w(uvw, gvi); // not re-normalised, :217
+							nr.ox = p.x; nr.oy = p.y; nr.oz = p.z; nr.tmin = tmin;
+							nr.dx = nd.x; nr.dy = nd.y; nr.dz = nd.z; nr.tmax = __int_as_float(0x7f800000);
+							survive = true;
+						}
+					}
+				} else {
+					if (respawn) st.beta *= ratio * fabsf(gvi.z);
+					const float prr = bounce > 6 ? 0.9f : 0.5f; // :304-310 / 454-460
+					if (!(rng_f32(st.rng) < prr)) {
+						st.beta /= (1.0f - prr);
+						if (respawn) {
+							const f3 nd = unit(l2w(uvw, gvi));
+							nr.ox = p.x; nr.oy = p.y; nr.oz = p.z; nr.tmin = tmin;
+							nr.dx = nd.x; nr.dy = nd.y; nr.dz = nd.z; nr.tmax = __int_as_float(0x7f800000);
+							st.band_bounce = band | ((bounce + 1) << 16);
+							survive = true;
+						}
+					}
+				}
+			}
+		}
+	}
+	const uint32_t s_next = queue_append(&counters->n_next, survive);
+	if (survive) { next_rays[s_next] = nr; next_state[s_next] = st; }
+	if (ALG != RT_ALG_NAIVE) {
+		const uint32_t s0 = queue_append(&counters->n_conn, want_c0);
+		if (want_c0) { conn_rays[s0] = cr0; conn[s0] = c0; }
+		const uint32_t s1 = queue_append(&counters->n_conn, want_c1);
+		if (want_c1) { conn_rays[s1] = cr1; conn[s1] = c1; }
+	}
+}
+
+// exact polygon test of one face, as light_objects[sel]->Hit(shadow_ray, ...) at renderer.cpp:278
+__device__ bool face_hit_exact(const DeviceGeom &g, const DeviceShade &sh, uint32_t face, const rt_ray &r, double tmin, double tmax)
+{
+#pragma clang fp contract(off)
+	const uint32_t t0 = sh.face_tri_begin[face], t1 = sh.face_tri_begin[face + 1];
+	const double ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
+	for (uint32_t t = t0; t < t1; t++) {
+		const uint32_t li = sh.tri_leaf[t];
+		const double2 a0 = g.tri_a[3 * (size_t)li], a1 = g.tri_a[3 * (size_t)li + 1], a2 = g.tri_a[3 * (size_t)li + 2];
+		const double2 b0 = g.tri_b[3 * (size_t)li], b1 = g.tri_b[3 * (size_t)li + 1], b2 = g.tri_b[3 * (size_t)li + 2];
+		const double v0x = a0.x, v0y = a0.y, v0z = a1.x, nx = a1.y, ny = a2.x, nz = a2.y;
+		const double v1x = b0.x, v1y = b0.y, v1z = b1.x, v2x = b1.y, v2y = b2.x, v2z = b2.y;
+		const double num = (v0x - ox) * nx + (v0y - oy) * ny + (v0z - oz) * nz;
+		const double den = dx * nx + dy * ny + dz * nz;
+		const double tt = num / den;
+		if (!(tt >= tmin && tt <= tmax)) continue;
+		const double px = ox + tt * dx, py = oy + tt * dy, pz = oz + tt * dz;
+		double ax = v1x - v0x, ay = v1y - v0y, az = v1z - v0z, bx = px - v1x, by = py - v1y, bz = pz - v1z;
+		const double r0x = ay * bz - az * by, r0y = -(ax * bz - az * bx), r0z = ax * by - ay * bx;
+		ax = v2x - v1x; ay = v2y - v1y; az = v2z - v1z; bx = px - v2x; by = py - v2y; bz = pz - v2z;
+		const double r1x = ay * bz - az * by, r1y = -(ax * bz - az * bx), r1z = ax * by - ay * bx;
+		ax = v0x - v2x; ay = v0y - v2y; az = v0z - v2z; bx = px - v0x; by = py - v0y; bz = pz - v0z;
+		const double r2x = ay * bz - az * by, r2y = -(ax * bz - az * bx), r2z = ax * by - ay * bx;
+		if (r0x * r1x + r0y * r1y + r0z * r1z > 0.0 && r1x * r2x + r1y * r2y + r1z * r2z > 0.0) return true;
+	}
+	return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// connect: turns visibility results into film contributions
+// ---------------------------------------------------------------------------------------------
+template <int ALG>
+__global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh, uint32_t n, const rt_ray *__restrict__ conn_rays,
+                                                    const ConnRec *__restrict__ conn, const rt_hit *__restrict__ conn_hits,
+                                                    const uint8_t *__restrict__ conn_any, float *__restrict__ film)
+{
+	const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+	if (idx >= n) return;
+	const ConnRec c = conn[idx];
+	const DevBand bd = sh.bands[c.band_kind & 0xFFFFu];
+	const uint32_t kind = c.band_kind >> 16;
+	if (ALG == RT_ALG_NEE) {
+		if (conn_any[idx]) return; // occluded, renderer.cpp:263
+		const rt_ray r = conn_rays[idx];
+		if (face_hit_exact(g, sh, c.sel_face, r, 0.0001, (double)c.c1 + 0.0001)) film_add(film, c.pixel, bd, c.c0);
+		return;
+	}
+	const rt_hit h = conn_hits[idx];
+	if (h.prim == RT_MISS || h.prim != c.sel_face) return; // renderer.cpp:373-376 / 419-421
+	const rt_ray r = conn_rays[idx];
+	const f3 o = F3(r.ox, r.oy, r.oz), d = F3(r.dx, r.dy, r.dz);
+	const f3 pl = o + h.t * d;
+	const TriShade tri = load_tri(sh.tri_shade, h.tri);
+	const f3 ln = shading_normal(tri, pl);
+	// GeometryTerm(light_rec, rec), renderer.cpp:784-789
+	const f3 v = o - pl;
+	const f3 dir = unit(v);
+	const f3 nrm = F3(c.nx, c.ny, c.nz);
+	const float G = fabsf(dot(dir, ln) * dot(dir, nrm) / dot(v, v));
+	const float light = mat_emitted(sh.materials[h.object], bd);
+	const float lpa = 1.0f / sh.face_area[c.sel_face] / (float)sh.n_lights;
+	float add;
+	if (kind == 0) add = power_heuristic2(lpa, c.c1 * G) * (c.c0 * G) * light;      // renderer.cpp:390-399
+	else add = power_heuristic2(G * c.c1, lpa) * c.c0 * light;                      // renderer.cpp:422-429
+	film_add(film, c.pixel, bd, add);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tonemap (renderer.cpp:124-143, spectrum.cpp:164-199)
+// ---------------------------------------------------------------------------------------------
+__constant__ float c_cie[3][RT_NBINS];
+
+__global__ void __launch_bounds__(kBlock) k_tonemap(const float *__restrict__ film, uint64_t npix, float scale, double *__restrict__ out)
+{
+	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (idx >= npix) return;
+	float X = 0.0f, Y = 0.0f, Z = 0.0f;
+	for (int i = 0; i < RT_NBINS; i++) {
+		const float s = film[idx * RT_NBINS + i] * scale;
+		X += s * c_cie[0][i] * 10.0f;
+		Y += s * c_cie[1][i] * 10.0f;
+		Z += s * c_cie[2][i] * 10.0f;
+	}
+	float rgb[3];
+	rgb[0] = 3.240479f * X + (-1.537150f) * Y + (-0.498535f) * Z;
+	rgb[1] = (-0.969256f) * X + 1.875991f * Y + 0.041556f * Z;
+	rgb[2] = 0.055648f * X + (-0.204043f) * Y + 1.057311f * Z;
+	for (int c = 0; c < 3; c++) {
+		float v = rgb[c];
+		v = v >= 0.0f ? fminf(powf(v, 1.0f / 2.2f), 1.0f) : 0.0f;
+		out[idx * 3 + c] = (double)v;
+	}
+}
+
+__global__ void __launch_bounds__(kBlock) k_film_to_f64(const float *__restrict__ film, uint64_t n, double *__restrict__ out)
+{
+	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (idx < n) out[idx] = (double)film[idx];
+}
+
+// CIE 1931 colour matching functions at 405..695 nm (CVRL tables, as reference spectrum.cpp:5-102)
+const float h_cie[3][RT_NBINS] = {
+	{4.742986E-02f, 1.446214E-01f, 2.488523E-01f, 3.227087E-01f, 3.418483E-01f, 2.826646E-01f, 2.219781E-01f, 1.29192E-01f,
+	 4.600865E-02f, 7.097731E-03f, 3.649178E-03f, 4.315171E-02f, 1.268468E-01f, 2.405015E-01f, 3.804244E-01f, 5.280233E-01f,
+	 7.016774E-01f, 8.853376E-01f, 1.051011E+00f, 1.14362E+00f, 1.134757E+00f, 1.007344E+00f, 8.135565E-01f, 5.75541E-01f,
+	 3.844986E-01f, 2.277792E-01f, 1.263808E-01f, 6.63996E-02f, 3.292138E-02f, 1.575417E-02f},
+	{4.971717E-03f, 1.429377E-02f, 2.612106E-02f, 4.15794E-02f, 5.743393E-02f, 7.238339E-02f, 1.060145E-01f, 1.535066E-01f,
+	 2.064828E-01f, 2.85068E-01f, 4.277595E-01f, 6.206256E-01f, 7.946448E-01f, 9.071347E-01f, 9.814106E-01f, 9.994608E-01f,
+	 9.902549E-01f, 9.424569E-01f, 8.587203E-01f, 7.544785E-01f, 6.270066E-01f, 4.89595E-01f, 3.609245E-01f, 2.416902E-01f,
+	 1.547397E-01f, 8.979594E-02f, 4.899699E-02f, 2.554223E-02f, 1.261573E-02f, 6.027677E-03f},
+	{2.369246E-01f, 7.378822E-01f, 1.305008E+00f, 1.74828E+00f, 1.918437E+00f, 1.664439E+00f, 1.42844E+00f, 9.991789E-01f,
+	 5.617313E-01f, 3.105939E-01f, 1.720018E-01f, 8.283548E-02f, 3.751912E-02f, 1.566174E-02f, 6.131421E-03f, 2.327186E-03f,
+	 8.822531E-04f, 3.386739E-04f, 1.335031E-04f, 5.460706E-05f, 2.334738E-05f, 1.048387E-05f, 0, 0, 0, 0, 0, 0, 0, 0}};
+
+#define HIP_TRY(expr)                                                                         \
+	do {                                                                                      \
+		hipError_t e_ = (expr);                                                               \
+		if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return e_; } \
+	} while (0)
+
+template <class T>
+hipError_t upload(T *&dst, const std::vector<T> &src, hipStream_t stream)
+{
+	if (dst) { (void)hipFree(dst); dst = nullptr; }
+	size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+	hipError_t e = hipMalloc((void **)&dst, bytes);
+	if (e != hipSuccess) return e;
+	if (!src.empty()) e = hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, stream);
+	if (e != hipSuccess) return e;
+	return hipStreamSynchronize(stream);
+}
+
+Impl *impl_of(RenderState &rs)
+{
+	if (!rs.impl) rs.impl = new Impl();
+	return static_cast<Impl *>(rs.impl);
+}
+
+DeviceShade make_shade(const Impl &im)
+{
+	DeviceShade sh;
+	sh.tri_shade = im.tri_shade;
+	sh.tri_face = im.tri_face;
+	sh.face_object = im.face_object;
+	sh.face_tri_begin = im.face_tri_begin;
+	sh.face_area = im.face_area;
+	sh.tri_cum = im.tri_cum;
+	sh.tri_leaf = im.tri_leaf;
+	sh.materials = im.materials;
+	sh.light_faces = im.light_faces;
+	sh.bands = im.bands;
+	sh.n_lights = im.n_lights;
+	sh.n_bands = im.n_bands;
+	return sh;
+}
+
+void free_queues(Impl &im)
+{
+	for (int k = 0; k < 2; k++) {
+		if (im.rays[k]) (void)hipFree(im.rays[k]);
+		if (im.state[k]) (void)hipFree(im.state[k]);
+		im.rays[k] = nullptr;
+		im.state[k] = nullptr;
+	}
+	if (im.hits) (void)hipFree(im.hits);
+	if (im.conn_rays) (void)hipFree(im.conn_rays);
+	if (im.conn) (void)hipFree(im.conn);
+	if (im.conn_hits) (void)hipFree(im.conn_hits);
+	if (im.conn_any) (void)hipFree(im.conn_any);
+	im.hits = nullptr; im.conn_rays = nullptr; im.conn = nullptr; im.conn_hits = nullptr; im.conn_any = nullptr;
+	im.capacity = 0;
+}
+
+} // namespace
+
+// fan triangle -> leaf order is filled by the caller through this hook (geometry upload knows the BVH)
+hipError_t render_upload_scene(RenderState &rs, const HostScene &host, const std::vector<uint32_t> &tri_leaf,
+                               const uint32_t *d_tri_face, const uint32_t *d_face_object, hipStream_t stream, std::string &err)
+{
+	Impl &im = *impl_of(rs);
+	std::vector<float4> ts(6 * host.n_tris);
+	for (uint64_t t = 0; t < host.n_tris; t++) {
+		const uint32_t f = host.tri_face[t];
+		const uint64_t b = host.face_begin[f], k = t - host.tri_begin[f];
+		const double *v0 = &host.pv[3 * b], *v1 = &host.pv[3 * (b + k + 1)], *v2 = &host.pv[3 * (b + k + 2)];
+		const double *n0 = &host.pn[3 * b], *n1 = &host.pn[3 * (b + k + 1)], *n2 = &host.pn[3 * (b + k + 2)];
+		const double *fn = &host.face_normal[3 * f];
+		// tri_area of HitTriangle (object.cpp:249): |cross(v1 - v0, v2 - v1)|
+		double ax = v1[0] - v0[0], ay = v1[1] - v0[1], az = v1[2] - v0[2], bx = v2[0] - v1[0], by = v2[1] - v1[1], bz = v2[2] - v1[2];
+		double cx = ay * bz - az * by, cy = -(ax * bz - az * bx), cz = ax * by - ay * bx;
+		double area2 = std::sqrt(cx * cx + cy * cy + cz * cz);
+		float4 *o = &ts[6 * t];
+		o[0] = make_float4((float)v0[0], (float)v0[1], (float)v0[2], (float)v1[0]);
+		o[1] = make_float4((float)v1[1], (float)v1[2], (float)v2[0], (float)v2[1]);
+		o[2] = make_float4((float)v2[2], (float)n0[0], (float)n0[1], (float)n0[2]);
+		o[3] = make_float4((float)n1[0], (float)n1[1], (float)n1[2], (float)n2[0]);
+		o[4] = make_float4((float)n2[1], (float)n2[2], (float)fn[0], (float)fn[1]);
+		o[5] = make_float4((float)fn[2], (float)area2, 0.0f, 0.0f);
+	}
+	std::vector<uint32_t> ftb(host.n_faces + 1);
+	for (uint64_t f = 0; f <= host.n_faces; f++) ftb[f] = (uint32_t)host.tri_begin[f];
+	std::vector<float> fa(host.n_faces), tc(host.n_tris);
+	for (uint64_t f = 0; f < host.n_faces; f++) fa[f] = (float)host.polygon_area[f];
+	for (uint64_t t = 0; t < host.n_tris; t++) tc[t] = (float)host.tri_cum[t];
+	HIP_TRY(upload(im.tri_shade, ts, stream));
+	HIP_TRY(upload(im.face_tri_begin, ftb, stream));
+	HIP_TRY(upload(im.face_area, fa, stream));
+	HIP_TRY(upload(im.tri_cum, tc, stream));
+	HIP_TRY(upload(im.tri_leaf, tri_leaf, stream));
+	im.tri_face = d_tri_face;
+	im.face_object = d_face_object;
+	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_cie), h_cie, sizeof(h_cie)));
+	return hipSuccess;
+}
+
+hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const std::vector<rt_material> &mats,
+                                   const std::vector<uint32_t> &light_faces, hipStream_t stream, std::string &err)
+{
+	(void)host;
+	Impl &im = *impl_of(rs);
+	std::vector<DevMaterial> dm(mats.size());
+	for (size_t i = 0; i < mats.size(); i++) {
+		dm[i].type = mats[i].type;
+		dm[i].light_flag = mats[i].light_flag;
+		for (int k = 0; k < RT_NBINS; k++) { dm[i].a[k] = (float)mats[i].a[k]; dm[i].b[k] = (float)mats[i].b[k]; }
+	}
+	HIP_TRY(upload(im.materials, dm, stream));
+	HIP_TRY(upload(im.light_faces, light_faces, stream));
+	im.n_lights = (uint32_t)light_faces.size();
+	return hipSuccess;
+}
+
+hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, int ns, int spectral_samples, int algorithm,
+                        uint64_t seed, void *d_film, hipStream_t stream, std::string &err)
+{
+	Impl &im = *impl_of(rs);
+	// band table, renderer.cpp:85-88 evaluated for every k in fp64
+	std::vector<DevBand> bands(spectral_samples);
+	for (int k = 0; k < spectral_samples; k++) {
+		double min_wl = 400.0 + 300.0 / spectral_samples * k;
+		double max_wl = min_wl + 300.0 / spectral_samples - 0.00001;
+		double central = (min_wl + max_wl) / 2.0;
+		DevBand &b = bands[k];
+		double lo = std::ceil((min_wl - 400) / 10), hi = std::floor((max_wl - 400) / 10);
+		b.min_i = (int)lo;
+		b.max_i = (int)hi;
+		if (b.min_i < 0 || b.max_i >= RT_NBINS) { err = "spectral band outside 400..700 nm"; return hipErrorInvalidValue; }
+		b.get_bin = (int)std::floor((central - 400) / 10);
+		b.flags = (b.min_i >= 1 ? 1 : 0) | (b.max_i <= RT_NBINS - 2 ? 2 : 0);
+		b.mod_min = (float)std::fmod(min_wl - 400, 10.0);
+		b.mod_max = (float)std::fmod(max_wl - 400, 10.0);
+		// LensMakersFormula + image distance, camera.h:161-163,197-200
+		double nl = cam.n[b.get_bin];
+		double focal = 1.0 / ((nl - 1) * cam.lens_maker_coefficient);
+		double a = 1.0 / (1.0 / focal - 1.0 / cam.d);
+		b.neg_a_over_d = (float)(-a / cam.d);
+		b.a_positive = a > 0.0 ? 1.0f : 0.0f;
+	}
+	HIP_TRY(upload(im.bands, bands, stream));
+	im.n_bands = (uint32_t)spectral_samples;
+	DevCamera &dc = im.cam;
+	for (int c = 0; c < 3; c++) {
+		dc.origin[c] = (float)cam.origin[c];
+		dc.llc_rel[c] = (float)(cam.film_lower_left_corner[c] - cam.origin[c]);
+		dc.horizontal[c] = (float)cam.horizontal[c];
+		dc.vertical[c] = (float)cam.vertical[c];
+		dc.w[c] = (float)cam.w[c];
+	}
+	dc.half_aperture = (float)(cam.aperture / 2.0);
+	double p_image = 1.0 / (cam.film_width * cam.film_height);              // camera.h:177
+	double p_lens = 1.0 / (M_PI * cam.aperture * cam.aperture / 4.0);        // camera.h:178
+	dc.weight_scale = (float)(cam.film_sensitivity / (cam.d * cam.d) / (p_image * p_lens)); // renderer.cpp:113-114
+
+	const size_t film_elems = (size_t)nx * ny * RT_NBINS;
+	if (rs.film_owned && rs.d_film) { (void)hipFree(rs.d_film); }
+	rs.d_film = nullptr;
+	rs.film_owned = false;
+	if (d_film) rs.d_film = (float *)d_film;
+	else {
+		HIP_TRY(hipMalloc((void **)&rs.d_film, film_elems * sizeof(float)));
+		rs.film_owned = true;
+	}
+	HIP_TRY(hipMemsetAsync(rs.d_film, 0, film_elems * sizeof(float), stream)); // renderer.cpp:58
+	if (!im.counters) {
+		HIP_TRY(hipMalloc((void **)&im.counters, sizeof(Counters)));
+		HIP_TRY(hipHostMalloc((void **)&im.h_counters, sizeof(Counters), hipHostMallocDefault));
+	}
+	rs.nx = nx; rs.ny = ny; rs.ns = ns; rs.spectral_samples = spectral_samples; rs.algorithm = algorithm; rs.seed = seed;
+	rs.closest_rays = rs.any_rays = rs.camera_samples = 0;
+	rs.begun = true;
+	return hipStreamSynchronize(stream);
+}
+
+static hipError_t ensure_queues(Impl &im, uint64_t cap, std::string &err)
+{
+	if (cap <= im.capacity) return hipSuccess;
+	free_queues(im);
+	for (int k = 0; k < 2; k++) {
+		HIP_TRY(hipMalloc((void **)&im.rays[k], cap * sizeof(rt_ray)));
+		HIP_TRY(hipMalloc((void **)&im.state[k], cap * sizeof(PathState)));
+	}
+	HIP_TRY(hipMalloc((void **)&im.hits, cap * sizeof(rt_hit)));
+	HIP_TRY(hipMalloc((void **)&im.conn_rays, 2 * cap * sizeof(rt_ray)));
+	HIP_TRY(hipMalloc((void **)&im.conn, 2 * cap * sizeof(ConnRec)));
+	HIP_TRY(hipMalloc((void **)&im.conn_hits, 2 * cap * sizeof(rt_hit)));
+	HIP_TRY(hipMalloc((void **)&im.conn_any, 2 * cap));
+	im.capacity = cap;
+	return hipSuccess;
+}
+
+template <int ALG>
+static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err)
+{
+	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_paths = npix * (uint64_t)n_samples;
+	const DeviceShade sh = make_shade(im);
+	const float tmin = ALG == RT_ALG_NEE ? 0.0001f : 0.001f; // renderer.cpp:173,235,337
+	hipLaunchKernelGGL(k_generate, dim3((unsigned)((n_paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands,
+	                   im.n_bands, rs.nx, rs.ny, rs.ns, first_sample, n_paths, rs.seed, tmin, im.rays[0], im.state[0]);
+	HIP_TRY(hipGetLastError());
+	rs.camera_samples += n_paths;
+	uint32_t n_active = (uint32_t)n_paths;
+	int cur = 0;
+	while (n_active > 0) {
+		HIP_TRY(launch_trace_closest(geom, im.rays[cur], n_active, im.hits, nullptr, stream));
+		rs.closest_rays += n_active;
+		HIP_TRY(hipMemsetAsync(im.counters, 0, 16, stream));
+		hipLaunchKernelGGL((k_shade<ALG>), dim3((n_active + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sh, n_active, im.rays[cur],
+		                   im.state[cur], im.hits, im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, im.conn, im.counters, rs.d_film);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(im.h_counters, im.counters, 16, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		const uint32_t n_next = im.h_counters->n_next, n_conn = im.h_counters->n_conn;
+		if (ALG != RT_ALG_NAIVE && n_conn > 0) {
+			if (ALG == RT_ALG_NEE) {
+				HIP_TRY(launch_trace_any(geom, im.conn_rays, n_conn, im.conn_any, stream));
+				rs.any_rays += n_conn;
+			} else {
+				HIP_TRY(launch_trace_closest(geom, im.conn_rays, n_conn, im.conn_hits, nullptr, stream));
+				rs.closest_rays += n_conn;
+			}
+			hipLaunchKernelGGL((k_connect<ALG>), dim3((n_conn + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, geom, sh, n_conn,
+			                   im.conn_rays, im.conn, im.conn_hits, im.conn_any, rs.d_film);
+			HIP_TRY(hipGetLastError());
+		}
+		n_active = n_next;
+		cur ^= 1;
+	}
+	return hipSuccess;
+}
+
+hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err)
+{
+	Impl &im = *impl_of(rs);
+	const uint64_t npix = (uint64_t)rs.nx * rs.ny;
+	// samples per batch: enough paths to fill the chip, bounded queue memory (<= 2^23 paths)
+	uint64_t per_batch = std::max<uint64_t>(1, (1ull << 23) / std::max<uint64_t>(npix, 1));
+	if (npix * per_batch >= (1ull << 31)) per_batch = 1;
+	if (npix >= (1ull << 31)) { err = "image too large for 32-bit path indices"; return hipErrorInvalidValue; }
+	HIP_TRY(ensure_queues(im, npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1)), err));
+	int s = first_sample, end = first_sample + n_samples;
+	while (s < end) {
+		int b = (int)std::min<uint64_t>(per_batch, (uint64_t)(end - s));
+		hipError_t e;
+		switch (rs.algorithm) {
+		case RT_ALG_NAIVE: e = run_batch<RT_ALG_NAIVE>(rs, im, geom, s, b, stream, err); break;
+		case RT_ALG_NEE: e = run_batch<RT_ALG_NEE>(rs, im, geom, s, b, stream, err); break;
+		default: e = run_batch<RT_ALG_MIS>(rs, im, geom, s, b, stream, err); break;
+		}
+		if (e != hipSuccess) return e;
+		s += b;
+	}
+	return hipSuccess;
+}
+
+hipError_t render_download_film(RenderState &rs, double *out, hipStream_t stream, std::string &err)
+{
+	const size_t n = (size_t)rs.nx * rs.ny * RT_NBINS;
+	double *d_tmp = nullptr;
+	HIP_TRY(hipMalloc((void **)&d_tmp, n * sizeof(double)));
+	hipLaunchKernelGGL(k_film_to_f64, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rs.d_film, (uint64_t)n, d_tmp);
+	hipError_t e = hipMemcpyAsync(out, d_tmp, n * sizeof(double), hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(stream);
+	(void)hipFree(d_tmp);
+	if (e != hipSuccess) err = std::string("film download: ") + hipGetErrorString(e);
+	return e;
+}
+
+hipError_t render_download_preview(RenderState &rs, int samples_done, double *out, hipStream_t stream, std::string &err)
+{
+	const size_t npix = (size_t)rs.nx * rs.ny;
+	double *d_tmp = nullptr;
+	HIP_TRY(hipMalloc((void **)&d_tmp, npix * 3 * sizeof(double)));
+	const float scale = (float)((double)rs.ns / (double)std::max(samples_done, 1)); // renderer.cpp:131
+	hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rs.d_film, (uint64_t)npix, scale, d_tmp);
+	hipError_t e = hipMemcpyAsync(out, d_tmp, npix * 3 * sizeof(double), hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(stream);
+	(void)hipFree(d_tmp);
+	if (e != hipSuccess) err = std::string("preview download: ") + hipGetErrorString(e);
+	return e;
+}
+
+void render_free(RenderState &rs)
+{
+	if (rs.impl) {
+		Impl &im = *static_cast<Impl *>(rs.impl);
+		free_queues(im);
+		if (im.tri_shade) (void)hipFree(im.tri_shade);
+		if (im.face_tri_begin) (void)hipFree(im.face_tri_begin);
+		if (im.tri_leaf) (void)hipFree(im.tri_leaf);
+		if (im.face_area) (void)hipFree(im.face_area);
+		if (im.tri_cum) (void)hipFree(im.tri_cum);
+		if (im.materials) (void)hipFree(im.materials);
+		if (im.light_faces) (void)hipFree(im.light_faces);
+		if (im.bands) (void)hipFree(im.bands);
+		if (im.counters) (void)hipFree(im.counters);
+		if (im.h_counters) (void)hipHostFree(im.h_counters);
+		delete &im;
+		rs.impl = nullptr;
+	}
+	if (rs.film_owned && rs.d_film) (void)hipFree(rs.d_film);
+	rs.d_film = nullptr;
+	rs.film_owned = false;
+	rs.begun = false;
+}
+
+} // namespace mi355rt

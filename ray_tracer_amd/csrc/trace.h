@@ -1,0 +1,11 @@
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_scene.h"
+#include "mi355rt.h"
+
+namespace mi355rt {
+// closest hit over n device-resident rays; d_t64 may be null
+hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, hipStream_t stream);
+// any hit: d_out[i] = 1 when some triangle is hit inside [tmin, tmax]
+hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, uint8_t *d_out, hipStream_t stream);
+} // namespace mi355rt

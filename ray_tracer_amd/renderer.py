@@ -1,0 +1,92 @@
+"""Host-side mirror of the reference `Renderer` (renderer.h:21-50): same member names, argument
+meaning and error behaviour, with the hot path running on the MI355X through the C ABI."""
+import numpy as np
+
+from . import capi
+from .camera import LensCamera
+from .scene_io import Obj
+
+Naive, NEE, MIS, NaiveBDPTType, MISBDPTType = range(5)  # enum RenderingAlgorithm, renderer.h:12-18
+
+
+class Renderer:
+    def __init__(self, device=0, seed=None):
+        self.ctx = capi.Context(device)
+        self.obj_loader = Obj()
+        self.cam = LensCamera()
+        self.algorithm_type = NaiveBDPTType  # renderer.h:33 (the GUI default; not implemented on the device)
+        self.spectrum_img = None  # [nx*ny, 30] float64, pixel index i*ny+j (renderer.cpp:116)
+        self.preview_img = None   # [nx*ny, 3] float64, gamma-encoded in [0, 1]
+        self.preview_img_flag = True
+        self.img_updated = False
+        self.rendering_runnnig = False  # spelling as in the reference (renderer.h:43)
+        self.stop_rendering = False
+        self.progress = 0.0
+        self.n_lights = 0
+        # the reference seeds mt19937 from random_device (renderer.cpp:14-15)
+        self.seed = int(np.random.SeedSequence().entropy & 0xFFFFFFFFFFFFFFFF) if seed is None else int(seed)
+        self.samples_per_pass = 1
+
+    def Load(self, objfilename):  # renderer.cpp:18-22 (the parser's bool is ignored there as well)
+        self.obj_loader = Obj()
+        self.obj_loader.Load(objfilename)
+        self.mesh = self.obj_loader.to_mesh()
+        self.ctx.upload_mesh(self.mesh)
+
+    def LoadMesh(self, mesh):
+        """Same as Load for a mesh already in memory (synthetic scenes)."""
+        self.obj_loader = Obj()
+        self.obj_loader.objects = [{"name": n, "faces": []} for n in mesh.get("names", [])]
+        self.mesh = mesh
+        self.ctx.upload_mesh(mesh)
+
+    def LoadMaterials(self, materials):  # renderer.cpp:24-44
+        """materials: {obj object name: NodeMaterial}.  False when an object has no entry or no
+        object is a light, as the reference returns."""
+        records = []
+        for name in self.obj_loader.object_names():
+            m = materials.get(name)
+            if m is None:
+                print("Material is unset for %s" % name)
+                return False
+            records.append(m.record())
+        try:
+            self.ctx.upload_materials(records)
+        except capi.BackendError as e:
+            if e.code in (capi.ERR_NO_LIGHTS, capi.ERR_NO_MATERIAL):
+                return False
+            raise
+        self.n_lights = self.ctx.stats()["n_lights"]
+        return True
+
+    def Clear(self):  # renderer.cpp:47-51
+        self.obj_loader.Clear()
+        self.img_updated = False
+
+    def RenderImage(self, nx, ny, ns, spectral_samples, enable_openmp=True, print_progress=False):  # renderer.cpp:54-160
+        if self.algorithm_type not in (Naive, NEE, MIS):
+            raise NotImplementedError("only Naive, NEE and MIS run on the device; the bidirectional integrators do not")
+        self.rendering_runnnig = True
+        self.ctx.set_camera(self.cam)
+        self.ctx.render_begin(nx, ny, ns, spectral_samples, self.algorithm_type, self.seed)
+        s = 0
+        while s < ns:
+            if self.stop_rendering:  # checked once per pass, renderer.cpp:70
+                break
+            b = min(max(1, self.samples_per_pass), ns - s)
+            self.ctx.render_pass(s, b)
+            self.ctx.render_sync()
+            s += b
+            if self.preview_img_flag or s == ns:
+                self.preview_img = self.ctx.download_preview(s)
+                self.img_updated = True
+            self.progress = float(s) / ns
+            if print_progress:
+                print("%g%%" % (self.progress * 100.0))
+        self.spectrum_img = self.ctx.download_film()
+        self.img_updated = True
+        if self.stop_rendering:
+            self.stop_rendering = False
+        self.rendering_runnnig = False
+        if print_progress:
+            print("Completed")
