@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X path-tracing backend.
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload (N=1): the Cornell box at 1920x1080 through the NEE+MIS wavefront integrator with 30
+spectral bands.  One step = one batch of `--spp-per-step` samples per pixel (default 4, i.e. 8.3 M
+camera samples, the batch the wavefront queues are sized for); K steps are timed after W warm-up
+steps; value = samples per pixel per second over all GPUs.  With N>1 every rank renders its own
+sample indices of the same image (weak scaling: K steps per rank) into its own film, and the films
+are summed with one RCCL all-reduce inside the timed region.
+
+The JSON line also carries
+  roofline      for the dominant kernel (closest-hit traversal): algorithmic bytes, i.e.
+                rays * (32 + 16 + 64*nodes_per_ray + 48*tris_per_ray), over the kernel's device time
+                measured with HIP events on its stream inside the timed region, against 8 TB/s;
+  cpu_baseline  the fp64 CPU restatement of the reference renderer (oracle/) timed on this host's
+                cores on a bounded sample of the same workload;
+  aux           the incoherent closest-hit rate on a 1M-triangle random soup with its own roofline figures.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # bytes/s
+
+
+def b_ray(nodes_per_ray, tris_per_ray):
+    """algorithmic bytes per closest-hit ray: ray in (32) + hit out (16) + 64 B per interior-node visit
+    + 48 B per triangle test of an ordered, t-pruned BVH2 walk"""
+    return 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * tris_per_ray
+
+
+def cpu_leg(args, ctx, capi, scenes, log):
+    """CPU side: (1) times the oracle's restatement of the reference renderer on a bounded sample of the
+    workload, (2) counts, with the oracle's ordered pruned BVH2 walk over the product's own tree, the
+    node visits and triangle tests per ray that the roofline's algorithmic bytes are built from."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1), os.cpu_count() or 1, 64))
+    out = {}
+    # ---- work units per ray on the render's own ray distribution (small render of the same scene/camera)
+    cx, cy = args.width // 10, args.height // 10
+    mesh, records, cam = scenes.cornell(cx, cy)
+    ctx.upload_mesh(mesh)
+    ctx.upload_materials(records)
+    ctx.set_camera(cam)
+    ctx.render_begin(cx, cy, 4, 30, capi.ALG_MIS, 1234)
+    finish = ctx.capture_rays(1 << 20)
+    ctx.render_pass(0, 4)
+    ctx.render_sync()
+    rays = finish()
+    sc = oracle.Scene(mesh)
+    nodes, tri_index = ctx.bvh2()
+    poly, tri, t, nv, nt = sc.trace_bvh2(nodes, tri_index, rays, nthreads=threads)
+    out["cornell_nodes_per_ray"] = nv / len(rays)
+    out["cornell_tris_per_ray"] = nt / len(rays)
+    out["cornell_rays_sampled"] = int(len(rays))
+    # GPU results on those rays must be the oracle's (a bench that measures wrong answers is worthless)
+    hits, t64 = ctx.trace_closest(rays, want_t64=True)
+    gp = hits["prim"].astype(np.int64)
+    gp[hits["prim"] == capi.MISS] = -1
+    out["cornell_parity_prim_mismatch"] = int((gp != poly).sum())
+    out["cornell_parity_t_mismatch"] = int((t64 != t).sum())
+    # ---- the reference algorithm on the CPU: same scene, same integrator, bounded sample
+    sc.set_materials(records)
+    oc = oracle.make_camera(cam)
+    oracle.lib().orc_camera_set_lens(ctypes.byref(oc), 60.0, 0.4)
+    oracle.lib().orc_camera_set_camera(ctypes.byref(oc), oracle._p(oracle.vec(0, 0, 3)), oracle._p(oracle.vec(0, 0, 2)),
+                                        oracle._p(oracle.vec(0, 1, 0)))
+    sx, sy, sspp = args.width // 2, args.height // 2, args.cpu_spp
+    mesh2, records2, cam2 = scenes.cornell(sx, sy)
+    oc.film_width = cam2.film_width
+    oracle.lib().orc_camera_set_lens(ctypes.byref(oc), 60.0, 0.4)
+    oracle.lib().orc_camera_set_camera(ctypes.byref(oc), oracle._p(oracle.vec(0, 0, 3)), oracle._p(oracle.vec(0, 0, 2)),
+                                        oracle._p(oracle.vec(0, 1, 0)))
+    sc.build_bvh()
+    t0 = time.time()
+    film, st = sc.render(oc, sx, sy, sspp, 30, oracle.ALG_MIS, seed=1, nthreads=threads)
+    dt = time.time() - t0
+    out["cpu"] = {
+        "value": st["samples"] / dt / (args.width * args.height), "unit": "spp/s at %dx%d" % (args.width, args.height),
+        "cores": threads, "kind": "port",
+        "sample": "%dx%d at %d spp (%d camera samples, %.1f s) of the same scene, camera and MIS integrator, "
+                  "fp64 restatement of the reference's unpruned BVH traversal and integrator, OpenMP" % (sx, sy, sspp, st["samples"], dt),
+        "msamples_per_s": st["samples"] / dt / 1e6, "rays_per_sample": st["closest_rays"] / st["samples"],
+    }
+    log("cpu leg: %s" % json.dumps(out))
+    return out, oracle
+
+
+def soup_leg(args, ctx, capi, synth, oracle, torch, rank, log):
+    """incoherent closest hit on a random soup: Mrays/s, work units per ray, fraction of the HBM roofline"""
+    n, sigma, m = args.soup_tris, args.soup_sigma, args.soup_rays
+    t0 = time.time()
+    mesh = synth.soup(n, sigma, seed=12345)
+    ctx.upload_mesh(mesh)
+    st = ctx.stats()
+    log("soup: %d triangles uploaded in %.1f s (host BVH build %.2f s, depth %d)" % (n, time.time() - t0, st["bvh_build_seconds"], st["bvh_depth"]))
+    rays = synth.incoherent_rays(m, seed=777, start=rank * m)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((m, 4), dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr())
+    ctx.render_sync()
+    ctx.profile_start()
+    reps = 5
+    for _ in range(reps):
+        ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr())
+    ctx.render_sync()
+    prof = ctx.profile_stop()["closest"]
+    res = {"triangles": n, "sigma": sigma, "rays_per_launch": m, "launches": reps,
+           "kernel_ms_per_launch": prof["ms"] / reps, "mrays_per_s": m * reps / (prof["ms"] * 1e-3) / 1e6,
+           "hit_rate": float((d_hits[:, 1] != -1).float().mean().item()), "bvh_build_s": st["bvh_build_seconds"],
+           "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"]}
+    if oracle is not None:
+        sc = oracle.Scene(mesh)
+        nodes, tri_index = ctx.bvh2()
+        sub = rays[:1 << 16]
+        poly, tri, t, nv, nt = sc.trace_bvh2(nodes, tri_index, sub)
+        h = d_hits[:len(sub)].cpu().numpy()
+        res["nodes_per_ray"], res["tris_per_ray"] = nv / len(sub), nt / len(sub)
+        res["b_ray"] = b_ray(res["nodes_per_ray"], res["tris_per_ray"])
+        res["achieved_gbs"] = res["mrays_per_s"] * 1e6 * res["b_ray"] / 1e9
+        res["frac_hbm"] = res["achieved_gbs"] * 1e9 / HBM_PEAK
+        res["parity_prim_mismatch"] = int((h[:, 1] != poly).sum())
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp-per-step", type=int, default=4)
+    ap.add_argument("--cpu-spp", type=int, default=8)
+    ap.add_argument("--soup-tris", type=int, default=1000000)
+    ap.add_argument("--soup-sigma", type=float, default=0.004)
+    ap.add_argument("--soup-rays", type=int, default=1 << 24)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (roofline then lacks the work-unit counts)")
+    ap.add_argument("--no-soup", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    from ray_tracer_amd import capi, scenes, synth
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the backend has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = capi.Context(local_rank)
+
+    cpu, oracle = (None, None)
+    if rank == 0 and args.gpus == 1 and not args.no_cpu:
+        cpu, oracle = cpu_leg(args, ctx, capi, scenes, log)
+
+    # ---------------- the timed workload ----------------
+    nx, ny, spp = args.width, args.height, args.spp_per_step
+    mesh, records, cam = scenes.cornell(nx, ny)
+    ctx.upload_mesh(mesh)
+    ctx.upload_materials(records)
+    ctx.set_camera(cam)
+    per_rank = (args.warmup + args.steps) * spp
+    ns_total = per_rank * world
+    film = torch.zeros(nx * ny * capi.NBINS, dtype=torch.float32, device="cuda")
+    ctx.render_begin(nx, ny, ns_total, 30, capi.ALG_MIS, 20261111, film.data_ptr())
+    first = rank * per_rank
+    for s in range(args.warmup):
+        ctx.render_pass(first + s * spp, spp)
+    ctx.render_sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ctx.profile_start()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, args.warmup + args.steps):
+        ctx.render_pass(first + s * spp, spp)
+    ctx.render_sync()
+    if world > 1:
+        dist.all_reduce(film)  # RCCL sum of the per-rank films over xGMI
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_stop()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stats = ctx.stats()
+    film_mean = float(film.sum().item()) / (nx * ny) * (ns_total / (per_rank * world))
+    ok = bool(torch.isfinite(film).all().item())
+
+    soup = None
+    if not args.no_soup:
+        soup = soup_leg(args, ctx, capi, synth, oracle, torch, rank, log)
+
+    if rank == 0:
+        k = prof["closest"]
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": "k_trace (closest hit)", "kernel_ms_avg": k["ms"] / max(k["launches"], 1), "launches": k["launches"],
+                "rays": k["items"], "kernel_ms_total": k["ms"], "mrays_per_s_in_kernel": k["items"] / max(k["ms"], 1e-9) / 1e3}
+        if cpu is not None:
+            bytes_per_ray = b_ray(cpu["cornell_nodes_per_ray"], cpu["cornell_tris_per_ray"])
+            roof["achieved"] = k["items"] * bytes_per_ray / (k["ms"] * 1e-3) / 1e9
+            roof["frac"] = roof["achieved"] * 1e9 / HBM_PEAK
+            roof["bytes_per_ray"] = bytes_per_ray
+            roof["nodes_per_ray"], roof["tris_per_ray"] = cpu["cornell_nodes_per_ray"], cpu["cornell_tris_per_ray"]
+        line = {
+            "metric": "spp/s at 1080p (Cornell box, NEE+MIS wavefront integrator); the incoherent closest-hit Mrays/s half of the metric is under aux",
+            "value": args.steps * spp * world / dt, "unit": "spp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 triangle test, f32 box test and shading", "data": "synthetic",
+            "config": {"workload": "Cornell box (example/cornell_box_triangulated.obj + materials.json) %dx%d, NEE+MIS, 30 spectral bands, "
+                                   "%d spp per step, %d spp timed per GPU" % (nx, ny, spp, args.steps * spp),
+                       "parallelism": "samples sharded over %d GPU(s), one RCCL all-reduce of the film" % world},
+            "msamples_per_s": args.steps * spp * world * nx * ny / dt / 1e6,
+            "rays_per_sample": (stats["closest_rays"] + stats["any_rays"]) / max(stats["camera_samples"], 1),
+            "kernels_ms": {name: v["ms"] for name, v in prof.items()},
+            "film_mean_per_pixel": film_mean, "film_finite": ok,
+            "roofline": roof,
+            "cpu_baseline": cpu["cpu"] if cpu is not None else None,
+            "aux": {"closest_hit_soup": soup, "parity_on_bench_rays": None if cpu is None else {
+                "prim_mismatch": cpu["cornell_parity_prim_mismatch"], "t_mismatch": cpu["cornell_parity_t_mismatch"],
+                "rays": cpu["cornell_rays_sampled"]}},
+        }
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

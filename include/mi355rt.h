@@ -173,6 +173,24 @@ int rt_download_preview(rt_context *ctx, int samples_done, double *preview_img);
 int rt_film_device_ptr(rt_context *ctx, void **d_film, size_t *bytes);
 
 /* ---- introspection (tests, roofline accounting) ---- */
+/* Per-kernel device time measured with HIP events recorded on the stream each kernel is launched on.
+ * items = rays for the two traversal kernels, paths / connections for the others. */
+typedef struct rt_kernel_time {
+	double ms;
+	uint64_t launches;
+	uint64_t items;
+} rt_kernel_time;
+typedef struct rt_profile {
+	rt_kernel_time closest, any, generate, shade, connect;
+} rt_profile;
+/* clears the accumulated times and starts recording an event pair around every kernel launch */
+int rt_profile_start(rt_context *ctx);
+/* waits for the recorded events, sums them per kernel and stops recording */
+int rt_profile_stop(rt_context *ctx, rt_profile *out);
+/* Diagnostic: while set, every ray a render pass traces (path and connection rays alike) is also copied
+ * to `buf` (caller-owned host memory, `capacity` rays) until it is full; *n_captured is updated as the
+ * pass runs.  NULL switches it off.  For sampling the traced ray distribution of a small render. */
+int rt_render_capture_rays(rt_context *ctx, rt_ray *buf, uint64_t capacity, uint64_t *n_captured);
 int rt_get_stats(rt_context *ctx, rt_stats *out);
 /* copies the host-built BVH2: nodes (n_nodes records) and tri_index (leaf order -> fan triangle).
  * Pass NULL pointers to query the counts only. */

@@ -17,7 +17,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_upload_materials", "rt_set_camera", "rt_clear",
     "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
     "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
-    "rt_get_stats", "rt_get_bvh2", "rt_stream",
+    "rt_get_stats", "rt_get_bvh2", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
 ]
 
 RAY_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("oz", "f4"), ("tmin", "f4"),
@@ -51,6 +51,15 @@ class Stats(C.Structure):
                 ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64), ("bvh_leaves", C.c_uint64),
                 ("bvh_build_seconds", C.c_double), ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64),
                 ("camera_samples", C.c_uint64), ("device_bytes", C.c_uint64)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("ms", C.c_double), ("launches", C.c_uint64), ("items", C.c_uint64)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("closest", KernelTime), ("any", KernelTime), ("generate", KernelTime), ("shade", KernelTime),
+                ("connect", KernelTime)]
 
 
 class BackendError(RuntimeError):
@@ -95,6 +104,9 @@ def load():
     lib.rt_get_bvh2.argtypes = [vp, vp, C.POINTER(u64), vp, C.POINTER(u64)]
     lib.rt_stream.argtypes = [vp]
     lib.rt_stream.restype = vp
+    lib.rt_profile_start.argtypes = [vp]
+    lib.rt_profile_stop.argtypes = [vp, C.POINTER(Profile)]
+    lib.rt_render_capture_rays.argtypes = [vp, vp, u64, C.POINTER(u64)]
     _lib = lib
     return lib
 
@@ -229,3 +241,25 @@ class Context:
 
     def stream(self):
         return self.lib.rt_stream(self.h)
+
+    def profile_start(self):
+        self._check(self.lib.rt_profile_start(self.h))
+
+    def profile_stop(self):
+        """{kernel: {ms, launches, items}} from HIP events recorded around every launch since profile_start"""
+        p = Profile()
+        self._check(self.lib.rt_profile_stop(self.h, C.byref(p)))
+        return {k: {"ms": getattr(p, k).ms, "launches": getattr(p, k).launches, "items": getattr(p, k).items}
+                for k in ("closest", "any", "generate", "shade", "connect")}
+
+    def capture_rays(self, capacity):
+        """starts copying every ray the next render passes trace into a host buffer; returns a function that
+        stops the capture and returns the rays"""
+        buf = np.zeros((capacity, 8), dtype=np.float32)
+        n = C.c_uint64()
+        self._check(self.lib.rt_render_capture_rays(self.h, _ptr(buf), capacity, C.byref(n)))
+
+        def finish():
+            self._check(self.lib.rt_render_capture_rays(self.h, None, 0, None))
+            return buf[:n.value]
+        return finish

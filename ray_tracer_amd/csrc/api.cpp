@@ -81,6 +81,7 @@ int rt_create(int device, rt_context **out)
 	rt_context *ctx = new (std::nothrow) rt_context();
 	if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "rt_create: out of host memory");
 	ctx->device = device;
+	ctx->render.profiler = &ctx->profiler;
 	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
 		std::string msg = std::string("rt_create: ") + hipGetErrorString(e);
 		delete ctx;
@@ -96,6 +97,7 @@ void rt_destroy(rt_context *ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	render_free(ctx->render);
+	ctx->profiler.destroy();
 	ctx->free_geometry();
 	if (ctx->d_stage_rays) (void)hipFree(ctx->d_stage_rays);
 	if (ctx->d_stage_out) (void)hipFree(ctx->d_stage_out);
@@ -204,7 +206,10 @@ int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, voi
 	if (n >= (1ull << 32) * 256ull) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_device: too many rays for one launch");
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-	if (ctx->fail_hip(launch_trace_closest(ctx->geom, (const rt_ray *)d_rays, n, (rt_hit *)d_hits, (double *)d_t64, s), "closest-hit launch")) return RT_ERR_HIP;
+	ctx->profiler.begin(Profiler::CLOSEST, n, s);
+	hipError_t e = launch_trace_closest(ctx->geom, (const rt_ray *)d_rays, n, (rt_hit *)d_hits, (double *)d_t64, s);
+	ctx->profiler.end(s);
+	if (ctx->fail_hip(e, "closest-hit launch")) return RT_ERR_HIP;
 	return RT_OK;
 }
 
@@ -214,7 +219,10 @@ int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any_device: no mesh uploaded");
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-	if (ctx->fail_hip(launch_trace_any(ctx->geom, (const rt_ray *)d_rays, n, (uint8_t *)d_out, s), "any-hit launch")) return RT_ERR_HIP;
+	ctx->profiler.begin(Profiler::ANY, n, s);
+	hipError_t e = launch_trace_any(ctx->geom, (const rt_ray *)d_rays, n, (uint8_t *)d_out, s);
+	ctx->profiler.end(s);
+	if (ctx->fail_hip(e, "any-hit launch")) return RT_ERR_HIP;
 	return RT_OK;
 }
 
@@ -343,5 +351,34 @@ int rt_get_bvh2(rt_context *ctx, rt_bvh2_node *nodes, uint64_t *n_nodes, uint32_
 }
 
 void *rt_stream(rt_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int rt_profile_start(rt_context *ctx)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	ctx->profiler.clear();
+	ctx->profiler.enabled = true;
+	return RT_OK;
+}
+
+int rt_profile_stop(rt_context *ctx, rt_profile *out)
+{
+	if (!ctx || !out) return RT_ERR_INVALID;
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	ctx->profiler.enabled = false;
+	ctx->profiler.collect(*out);
+	return RT_OK;
+}
+
+int rt_render_capture_rays(rt_context *ctx, rt_ray *buf, uint64_t capacity, uint64_t *n_captured)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	ctx->render.capture_buf = buf;
+	ctx->render.capture_capacity = buf ? capacity : 0;
+	ctx->render.capture_count = 0;
+	ctx->render.capture_count_out = buf ? n_captured : nullptr;
+	if (n_captured) *n_captured = 0;
+	return RT_OK;
+}
 
 } // extern "C"

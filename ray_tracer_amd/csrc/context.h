@@ -34,6 +34,7 @@ struct rt_context {
 	rt_camera camera{};
 
 	mi355rt::RenderState render;
+	mi355rt::Profiler profiler;
 
 	bool fail_hip(hipError_t e, const char *what);
 	void free_geometry();

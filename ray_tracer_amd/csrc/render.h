@@ -10,6 +10,60 @@
 
 namespace mi355rt {
 
+// HIP-event timing of individual kernel launches on the stream they run on.
+struct Profiler {
+	enum Kind { CLOSEST = 0, ANY, GENERATE, SHADE, CONNECT, N_KINDS };
+	struct Rec { int kind; uint64_t items; hipEvent_t start, stop; };
+	bool enabled = false;
+	std::vector<Rec> recs;
+	std::vector<hipEvent_t> pool; // events free for reuse
+	hipEvent_t get()
+	{
+		if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+		hipEvent_t e = nullptr;
+		(void)hipEventCreate(&e);
+		return e;
+	}
+	// call begin() right before a launch and end() right after it
+	void begin(int kind, uint64_t items, hipStream_t s)
+	{
+		if (!enabled) return;
+		Rec r{kind, items, get(), get()};
+		(void)hipEventRecord(r.start, s);
+		recs.push_back(r);
+	}
+	void end(hipStream_t s)
+	{
+		if (!enabled) return;
+		(void)hipEventRecord(recs.back().stop, s);
+	}
+	void clear()
+	{
+		for (auto &r : recs) { pool.push_back(r.start); pool.push_back(r.stop); }
+		recs.clear();
+	}
+	void collect(rt_profile &out)
+	{
+		rt_kernel_time *k[N_KINDS] = {&out.closest, &out.any, &out.generate, &out.shade, &out.connect};
+		for (int i = 0; i < N_KINDS; i++) *k[i] = rt_kernel_time{0.0, 0, 0};
+		for (auto &r : recs) {
+			(void)hipEventSynchronize(r.stop);
+			float ms = 0.0f;
+			(void)hipEventElapsedTime(&ms, r.start, r.stop);
+			k[r.kind]->ms += ms;
+			k[r.kind]->launches++;
+			k[r.kind]->items += r.items;
+		}
+		clear();
+	}
+	void destroy()
+	{
+		clear();
+		for (auto e : pool) (void)hipEventDestroy(e);
+		pool.clear();
+	}
+};
+
 struct RenderState {
 	// film
 	int nx = 0, ny = 0, ns = 0, spectral_samples = 0, algorithm = 0;
@@ -19,6 +73,11 @@ struct RenderState {
 	bool begun = false;
 	// counters since rt_render_begin
 	uint64_t closest_rays = 0, any_rays = 0, camera_samples = 0;
+	Profiler *profiler = nullptr;   // owned by the context
+	// diagnostic ray capture
+	rt_ray *capture_buf = nullptr;
+	uint64_t capture_capacity = 0, capture_count = 0;
+	uint64_t *capture_count_out = nullptr;
 	// opaque device allocations managed by render.hip
 	void *impl = nullptr;
 };

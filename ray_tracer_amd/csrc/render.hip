@@ -812,32 +812,56 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_paths = npix * (uint64_t)n_samples;
 	const DeviceShade sh = make_shade(im);
 	const float tmin = ALG == RT_ALG_NEE ? 0.0001f : 0.001f; // renderer.cpp:173,235,337
+	Profiler nop, &prof = rs.profiler ? *rs.profiler : nop;
+	auto capture = [&](const rt_ray *d, uint64_t n) -> hipError_t {
+		if (!rs.capture_buf || rs.capture_count >= rs.capture_capacity) return hipSuccess;
+		uint64_t k = std::min<uint64_t>(n, rs.capture_capacity - rs.capture_count);
+		hipError_t e = hipMemcpyAsync(rs.capture_buf + rs.capture_count, d, k * sizeof(rt_ray), hipMemcpyDeviceToHost, stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(stream);
+		rs.capture_count += k;
+		if (rs.capture_count_out) *rs.capture_count_out = rs.capture_count;
+		return e;
+	};
+	prof.begin(Profiler::GENERATE, n_paths, stream);
 	hipLaunchKernelGGL(k_generate, dim3((unsigned)((n_paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands,
 	                   im.n_bands, rs.nx, rs.ny, rs.ns, first_sample, n_paths, rs.seed, tmin, im.rays[0], im.state[0]);
+	prof.end(stream);
 	HIP_TRY(hipGetLastError());
 	rs.camera_samples += n_paths;
 	uint32_t n_active = (uint32_t)n_paths;
 	int cur = 0;
 	while (n_active > 0) {
+		HIP_TRY(capture(im.rays[cur], n_active));
+		prof.begin(Profiler::CLOSEST, n_active, stream);
 		HIP_TRY(launch_trace_closest(geom, im.rays[cur], n_active, im.hits, nullptr, stream));
+		prof.end(stream);
 		rs.closest_rays += n_active;
 		HIP_TRY(hipMemsetAsync(im.counters, 0, 16, stream));
+		prof.begin(Profiler::SHADE, n_active, stream);
 		hipLaunchKernelGGL((k_shade<ALG>), dim3((n_active + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sh, n_active, im.rays[cur],
 		                   im.state[cur], im.hits, im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, im.conn, im.counters, rs.d_film);
+		prof.end(stream);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(im.h_counters, im.counters, 16, hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
 		const uint32_t n_next = im.h_counters->n_next, n_conn = im.h_counters->n_conn;
 		if (ALG != RT_ALG_NAIVE && n_conn > 0) {
+			HIP_TRY(capture(im.conn_rays, n_conn));
 			if (ALG == RT_ALG_NEE) {
+				prof.begin(Profiler::ANY, n_conn, stream);
 				HIP_TRY(launch_trace_any(geom, im.conn_rays, n_conn, im.conn_any, stream));
+				prof.end(stream);
 				rs.any_rays += n_conn;
 			} else {
+				prof.begin(Profiler::CLOSEST, n_conn, stream);
 				HIP_TRY(launch_trace_closest(geom, im.conn_rays, n_conn, im.conn_hits, nullptr, stream));
+				prof.end(stream);
 				rs.closest_rays += n_conn;
 			}
+			prof.begin(Profiler::CONNECT, n_conn, stream);
 			hipLaunchKernelGGL((k_connect<ALG>), dim3((n_conn + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, geom, sh, n_conn,
 			                   im.conn_rays, im.conn, im.conn_hits, im.conn_any, rs.d_film);
+			prof.end(stream);
 			HIP_TRY(hipGetLastError());
 		}
 		n_active = n_next;

@@ -210,19 +210,8 @@ def make_camera(py_cam):
 
 def cornell_setup(cornell_dir, nx, ny, vfov=60.0, focal_length=0.4, obj_name="cornell_box_triangulated.obj"):
     """The benchmark scene: mesh tables, material records per object, python camera, oracle camera."""
-    from ray_tracer_amd import scene_io
-    from ray_tracer_amd.camera import LensCamera
-    o = scene_io.Obj()
-    assert o.Load(os.path.join(cornell_dir, obj_name))
-    mesh = o.to_mesh()
-    mats = scene_io.load_materials(os.path.join(cornell_dir, "materials.json"))
-    omm = scene_io.load_objmatmap(os.path.join(cornell_dir, "objmatmap.json"))
-    records = [mats[omm[name]].record() for name in mesh["names"]]
-    cam = LensCamera()
-    cam.film_height = 0.024
-    cam.film_width = 0.024 * nx / ny  # the GUI rule, scene.cpp:668
-    cam.SetLens(vfov, focal_length)
-    cam.set_Camera([0, 0, 3], [0, 0, 2], [0, 1, 0])  # pos, pos+front, up (scene.cpp:867)
+    from ray_tracer_amd import scenes
+    mesh, records, cam = scenes.cornell(nx, ny, vfov, focal_length, obj_name, cornell_dir)
     oc = make_camera(cam)
     lib().orc_camera_set_lens(C.byref(oc), vfov, focal_length)
     lib().orc_camera_set_camera(C.byref(oc), _p(vec(0, 0, 3)), _p(vec(0, 0, 2)), _p(vec(0, 1, 0)))
