@@ -69,10 +69,13 @@ struct ConnRec {
 	uint32_t sel_face, pixel, band_kind; // band | kind << 16; kind 0: MIS light sample, 1: MIS bsdf sample, 2: NEE
 };
 
+// queue tails packed in one 64-bit word (low: continuation rays, high: connection rays) so that a
+// workgroup reserves its slots in both queues with a single atomic
 struct Counters {
-	uint32_t n_next, n_conn, pad0, pad1;
-	unsigned long long closest_rays, any_rays;
+	unsigned long long tails;
+	unsigned long long pad;
 };
+constexpr int kShadeBlock = 1024;
 
 struct Impl {
 	// shading data
@@ -299,18 +302,43 @@ __device__ __forceinline__ f3 shading_normal(const TriShade &t, f3 p)
 	return F3(s.x / t.area2, s.y / t.area2, s.z / t.area2);
 }
 
-// wave-aggregated append: one atomic per wave, returns this lane's slot (or ~0u when !want)
-__device__ __forceinline__ uint32_t queue_append(uint32_t *counter, bool want)
+// Workgroup-aggregated queue reservation: every lane asks for `survive` (0/1) continuation slots and
+// for up to two connection slots; one 64-bit atomic per workgroup reserves both ranges.  (One atomic
+// per wave on a single address serialises at ~10 ns each and dominated the shade kernel.)
+struct Slots { uint32_t next, c0, c1; };
+__device__ __forceinline__ Slots reserve_slots(unsigned long long *tails, bool survive, bool want_c0, bool want_c1)
 {
-	const unsigned long long mask = __ballot(want);
-	if (mask == 0) return 0xFFFFFFFFu;
-	const int lane = threadIdx.x & 63;
-	const int leader = __ffsll((long long)mask) - 1;
-	uint32_t base = 0;
-	if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-	base = __shfl(base, leader);
-	const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-	return want ? base + rank : 0xFFFFFFFFu;
+	__shared__ uint32_t s_next[kShadeBlock / 64], s_conn[kShadeBlock / 64];
+	__shared__ uint32_t s_base_next, s_base_conn;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	const unsigned long long ms = __ballot(survive), m0 = __ballot(want_c0), m1 = __ballot(want_c1);
+	if (lane == 0) {
+		s_next[wave] = (uint32_t)__popcll(ms);
+		s_conn[wave] = (uint32_t)(__popcll(m0) + __popcll(m1));
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t an = 0, ac = 0;
+		const int nw = (blockDim.x + 63) >> 6;
+		for (int w = 0; w < nw; w++) {
+			const uint32_t tn = s_next[w], tc = s_conn[w];
+			s_next[w] = an;
+			s_conn[w] = ac;
+			an += tn;
+			ac += tc;
+		}
+		unsigned long long base = 0;
+		if (an | ac) base = atomicAdd(tails, (unsigned long long)an | ((unsigned long long)ac << 32));
+		s_base_next = (uint32_t)base;
+		s_base_conn = (uint32_t)(base >> 32);
+	}
+	__syncthreads();
+	Slots r;
+	r.next = s_base_next + s_next[wave] + (uint32_t)__popcll(ms & lt);
+	r.c0 = s_base_conn + s_conn[wave] + (uint32_t)__popcll(m0 & lt);
+	r.c1 = s_base_conn + s_conn[wave] + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lt);
+	return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -364,13 +392,13 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBan
 // the reference's order; appends connection rays and the continuation ray.
 // ---------------------------------------------------------------------------------------------
 template <int ALG>
-__global__ void __launch_bounds__(kBlock) k_shade(DeviceShade sh, uint32_t n, const rt_ray *__restrict__ rays,
+__global__ void __launch_bounds__(kShadeBlock) k_shade(DeviceShade sh, uint32_t n, const rt_ray *__restrict__ rays,
                                                   const PathState *__restrict__ state, const rt_hit *__restrict__ hits,
                                                   rt_ray *__restrict__ next_rays, PathState *__restrict__ next_state,
                                                   rt_ray *__restrict__ conn_rays, ConnRec *__restrict__ conn,
                                                   Counters *__restrict__ counters, float *__restrict__ film)
 {
-	const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
 	const bool live = idx < n;
 	bool survive = false, want_c0 = false, want_c1 = false;
 	rt_ray nr{}, cr0{}, cr1{};
@@ -486,13 +514,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceShade sh, uint32_t n, co
 			}
 		}
 	}
-	const uint32_t s_next = queue_append(&counters->n_next, survive);
-	if (survive) { next_rays[s_next] = nr; next_state[s_next] = st; }
+	const Slots sl = reserve_slots(&counters->tails, survive, want_c0, want_c1);
+	if (survive) { next_rays[sl.next] = nr; next_state[sl.next] = st; }
 	if (ALG != RT_ALG_NAIVE) {
-		const uint32_t s0 = queue_append(&counters->n_conn, want_c0);
-		if (want_c0) { conn_rays[s0] = cr0; conn[s0] = c0; }
-		const uint32_t s1 = queue_append(&counters->n_conn, want_c1);
-		if (want_c1) { conn_rays[s1] = cr1; conn[s1] = c1; }
+		if (want_c0) { conn_rays[sl.c0] = cr0; conn[sl.c0] = c0; }
+		if (want_c1) { conn_rays[sl.c1] = cr1; conn[sl.c1] = c1; }
 	}
 }
 
@@ -838,13 +864,13 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 		rs.closest_rays += n_active;
 		HIP_TRY(hipMemsetAsync(im.counters, 0, 16, stream));
 		prof.begin(Profiler::SHADE, n_active, stream);
-		hipLaunchKernelGGL((k_shade<ALG>), dim3((n_active + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sh, n_active, im.rays[cur],
+		hipLaunchKernelGGL((k_shade<ALG>), dim3((n_active + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, stream, sh, n_active, im.rays[cur],
 		                   im.state[cur], im.hits, im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, im.conn, im.counters, rs.d_film);
 		prof.end(stream);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(im.h_counters, im.counters, 16, hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
-		const uint32_t n_next = im.h_counters->n_next, n_conn = im.h_counters->n_conn;
+		const uint32_t n_next = (uint32_t)im.h_counters->tails, n_conn = (uint32_t)(im.h_counters->tails >> 32);
 		if (ALG != RT_ALG_NAIVE && n_conn > 0) {
 			HIP_TRY(capture(im.conn_rays, n_conn));
 			if (ALG == RT_ALG_NEE) {

@@ -2,7 +2,7 @@
 import sys, time, os
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ray_tracer_amd import capi, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 sigma = float(sys.argv[2]) if len(sys.argv) > 2 else 0.004
