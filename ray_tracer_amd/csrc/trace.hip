@@ -23,7 +23,7 @@ constexpr int kScratchStack = 96; // deeper trees (bounded by the builder)
 
 struct RayD {
 	double ox, oy, oz, dx, dy, dz, tmin;
-};
+}; // the float ray widened to double: the same values the reference computes with
 
 // The reference's plane distance: t = dot(v0 - o, n) / dot(d, n)   (object.cpp:244)
 __device__ __forceinline__ double plane_t(const RayD &r, double v0x, double v0y, double v0z, double nx, double ny, double nz)
@@ -67,116 +67,194 @@ __device__ __forceinline__ float next_up(float x) // smallest float > x for fini
 	return __int_as_float(i);
 }
 
+constexpr int kDone = (int)0x80000000; // no leaf link has this value (first < 2^27 and count <= 16)
+constexpr int kRefillMin = 16;          // idle lanes in a wave before it takes new rays
+
+// Persistent waves: each wave owns a contiguous range of rays and keeps its 64 lanes busy by handing
+// idle lanes the next rays of the range (no global work counter, so no same-address atomics).
+// Traversal is "while-while" with one postponed leaf per lane: a lane that reaches a leaf parks it and
+// keeps descending until it reaches a second leaf or runs out of nodes, so the expensive fp64 triangle
+// phase runs with most lanes holding work.
 template <bool LDS_STACK, bool ANY>
 __global__ void __launch_bounds__(kBlock) k_trace(DeviceGeom g, const rt_ray *__restrict__ rays, uint64_t n,
                                                   rt_hit *__restrict__ hits, double *__restrict__ t64,
-                                                  uint8_t *__restrict__ any_out)
+                                                  uint8_t *__restrict__ any_out, uint32_t rays_per_wave)
 {
 	__shared__ int lds_stack[LDS_STACK ? kLdsStack * kBlock : 1];
 	int scratch_stack[LDS_STACK ? 1 : kScratchStack];
-	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-	if (i >= n) return;
+	const int lane = threadIdx.x & 63;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	uint64_t next = wave_id * rays_per_wave;
+	const uint64_t end = next + rays_per_wave < n ? next + rays_per_wave : n;
 
-	const float4 ra = reinterpret_cast<const float4 *>(rays)[2 * i];
-	const float4 rb = reinterpret_cast<const float4 *>(rays)[2 * i + 1];
-	RayD r;
-	r.ox = ra.x; r.oy = ra.y; r.oz = ra.z; r.tmin = ra.w;
-	r.dx = rb.x; r.dy = rb.y; r.dz = rb.z;
-	double t_best = isinf(rb.w) ? DBL_MAX : (double)rb.w; // t_max; shrinks to the closest accepted t
-	uint32_t best = RT_MISS;                               // leaf-order index of the closest triangle
-	uint32_t best_tri = RT_MISS;                           // its fan-triangle id (tie rule: lowest wins)
-
-	const float ox = ra.x, oy = ra.y, oz = ra.z;
-	const float ix = 1.0f / rb.x, iy = 1.0f / rb.y, iz = 1.0f / rb.z;
-	const float tmin_f = ra.w;
-	float tfar_f = rb.w; // float bound >= t_best
+	bool active = false;
+	uint64_t ray_id = 0;
+	float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tmin_f = 0, tfar_f = 0;
+	double t_best = 0.0;
+	uint32_t best = RT_MISS, best_tri = RT_MISS;
 	bool found_any = false;
+	int sp = 0, cur = kDone, leaf = 0;
 
-	int sp = 0;
-	int cur = 0;
 	for (;;) {
-		if (cur >= 0) {
-			const float4 q0 = g.nodes[4 * (size_t)cur], q1 = g.nodes[4 * (size_t)cur + 1];
-			const float4 q2 = g.nodes[4 * (size_t)cur + 2], q3 = g.nodes[4 * (size_t)cur + 3];
-			// child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
-			float a0 = (q0.x - ox) * ix, b0 = (q0.w - ox) * ix;
-			float a1 = (q0.y - oy) * iy, b1 = (q1.x - oy) * iy;
-			float a2 = (q0.z - oz) * iz, b2 = (q1.y - oz) * iz;
-			float n0 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), tmin_f));
-			float f0 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), tfar_f));
-			a0 = (q1.z - ox) * ix; b0 = (q2.y - ox) * ix;
-			a1 = (q1.w - oy) * iy; b1 = (q2.z - oy) * iy;
-			a2 = (q2.x - oz) * iz; b2 = (q2.w - oz) * iz;
-			float n1 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), tmin_f));
-			float f1 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), tfar_f));
-			// slack: each slab distance carries <= 3 roundings (2^-24 each)
-			const bool h0 = n0 <= fmaf(fabsf(f0), 1e-6f, f0);
-			const bool h1 = n1 <= fmaf(fabsf(f1), 1e-6f, f1);
-			const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-			if (h0 && h1) {
-				const bool swap = n1 < n0;
-				const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-				if (LDS_STACK) lds_stack[sp * kBlock + threadIdx.x] = farc;
-				else scratch_stack[sp] = farc;
-				sp++;
-				cur = nearc;
-				continue;
-			} else if (h0) {
-				cur = c0;
-				continue;
-			} else if (h1) {
-				cur = c1;
-				continue;
+		// ---- hand new rays to idle lanes
+		const unsigned long long idle = __ballot(!active);
+		if (idle != 0 && next < end) {
+			const int nidle = __popcll(idle);
+			if (nidle >= kRefillMin) {
+				const uint64_t mine = next + (uint64_t)__popcll(idle & lt);
+				if (!active && mine < end) {
+					const float4 ra = reinterpret_cast<const float4 *>(rays)[2 * mine];
+					const float4 rb = reinterpret_cast<const float4 *>(rays)[2 * mine + 1];
+					ray_id = mine;
+					ox = ra.x; oy = ra.y; oz = ra.z; tmin_f = ra.w;
+					dx = rb.x; dy = rb.y; dz = rb.z; tfar_f = rb.w;
+					ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+					t_best = isinf(rb.w) ? DBL_MAX : (double)rb.w; // t_max; shrinks to the closest accepted t
+					best = RT_MISS;
+					best_tri = RT_MISS;
+					found_any = false;
+					sp = 0;
+					cur = 0;
+					leaf = 0;
+					active = true;
+				}
+				next += (uint64_t)nidle;
 			}
-		} else {
-			const uint32_t c = (uint32_t)~cur;
-			const uint32_t first = c & 0x07FFFFFFu, count = (c >> 27) + 1u;
-			for (uint32_t k = 0; k < count; k++) {
-				const uint32_t li = first + k;
-				const double2 a0 = g.tri_a[3 * (size_t)li], a1 = g.tri_a[3 * (size_t)li + 1], a2 = g.tri_a[3 * (size_t)li + 2];
-				// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz)
-				const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
-				if (!(t >= r.tmin && t <= t_best)) continue;
-				const double2 b0 = g.tri_b[3 * (size_t)li], b1 = g.tri_b[3 * (size_t)li + 1], b2 = g.tri_b[3 * (size_t)li + 2];
-				// b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
-				if (!inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) continue;
-				if (ANY) { found_any = true; break; }
-				const uint32_t tri = g.leaf_tri[li];
-				if (t < t_best || best == RT_MISS || tri < best_tri) {
-					t_best = t;
-					best = li;
-					best_tri = tri;
-					float tf = (float)t;
-					if ((double)tf < t) tf = next_up(tf);
-					tfar_f = tf;
+		}
+		if (__ballot(active) == 0) break;
+		if (active) {
+			// ---- node phase: descend until this lane holds a parked leaf and stands on another, or is out of nodes
+			while (cur >= 0) {
+				const float4 q0 = g.nodes[4 * (size_t)cur], q1 = g.nodes[4 * (size_t)cur + 1];
+				const float4 q2 = g.nodes[4 * (size_t)cur + 2], q3 = g.nodes[4 * (size_t)cur + 3];
+				// child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
+				float a0 = (q0.x - ox) * ix, b0 = (q0.w - ox) * ix;
+				float a1 = (q0.y - oy) * iy, b1 = (q1.x - oy) * iy;
+				float a2 = (q0.z - oz) * iz, b2 = (q1.y - oz) * iz;
+				const float n0 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), tmin_f));
+				const float f0 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), tfar_f));
+				a0 = (q1.z - ox) * ix; b0 = (q2.y - ox) * ix;
+				a1 = (q1.w - oy) * iy; b1 = (q2.z - oy) * iy;
+				a2 = (q2.x - oz) * iz; b2 = (q2.w - oz) * iz;
+				const float n1 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), tmin_f));
+				const float f1 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), tfar_f));
+				// slack: each slab distance carries <= 3 roundings (2^-24 each)
+				const bool h0 = n0 <= fmaf(fabsf(f0), 1e-6f, f0);
+				const bool h1 = n1 <= fmaf(fabsf(f1), 1e-6f, f1);
+				const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+				if (h0 && h1) {
+					const bool swap = n1 < n0;
+					const int farc = swap ? c0 : c1;
+					if (LDS_STACK) lds_stack[sp * kBlock + threadIdx.x] = farc;
+					else scratch_stack[sp] = farc;
+					sp++;
+					cur = swap ? c1 : c0;
+				} else if (h0) {
+					cur = c0;
+				} else if (h1) {
+					cur = c1;
+				} else if (sp == 0) {
+					cur = kDone;
+				} else {
+					sp--;
+					cur = LDS_STACK ? lds_stack[sp * kBlock + threadIdx.x] : scratch_stack[sp];
+				}
+				if (cur < 0 && cur != kDone && leaf == 0) { // park the first leaf and keep going
+					leaf = cur;
+					if (sp == 0) cur = kDone;
+					else {
+						sp--;
+						cur = LDS_STACK ? lds_stack[sp * kBlock + threadIdx.x] : scratch_stack[sp];
+					}
+				}
+				if (__ballot(leaf == 0) == 0) break; // every lane still descending already holds a leaf
+			}
+			// ---- leaf phase: the parked leaf, then the leaf this lane stands on (if any)
+			if (leaf == 0 && cur < 0 && cur != kDone) {
+				leaf = cur;
+				if (sp == 0) cur = kDone;
+				else {
+					sp--;
+					cur = LDS_STACK ? lds_stack[sp * kBlock + threadIdx.x] : scratch_stack[sp];
 				}
 			}
-			if (ANY && found_any) break;
+			while (leaf != 0) {
+				const uint32_t c = (uint32_t)~leaf;
+				const uint32_t first = c & 0x07FFFFFFu, count = (c >> 27) + 1u;
+				RayD r;
+				r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz; r.tmin = tmin_f;
+				for (uint32_t k = 0; k < count; k++) {
+					const uint32_t li = first + k;
+					const double2 a0 = g.tri_a[3 * (size_t)li], a1 = g.tri_a[3 * (size_t)li + 1], a2 = g.tri_a[3 * (size_t)li + 2];
+					// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz)
+					const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
+					if (!(t >= r.tmin && t <= t_best)) continue;
+					const double2 b0 = g.tri_b[3 * (size_t)li], b1 = g.tri_b[3 * (size_t)li + 1], b2 = g.tri_b[3 * (size_t)li + 2];
+					// b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
+					if (!inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) continue;
+					if (ANY) { found_any = true; break; }
+					const uint32_t tri = g.leaf_tri[li];
+					if (t < t_best || best == RT_MISS || tri < best_tri) { // ties in t: lowest fan triangle
+						t_best = t;
+						best = li;
+						best_tri = tri;
+						float tf = (float)t;
+						if ((double)tf < t) tf = next_up(tf);
+						tfar_f = tf;
+					}
+				}
+				leaf = 0;
+				if (ANY && found_any) { cur = kDone; break; }
+				if (cur < 0 && cur != kDone) {
+					leaf = cur;
+					if (sp == 0) cur = kDone;
+					else {
+						sp--;
+						cur = LDS_STACK ? lds_stack[sp * kBlock + threadIdx.x] : scratch_stack[sp];
+					}
+				}
+			}
+			// ---- finished: write the result, free the lane
+			if (cur == kDone) {
+				if (ANY) {
+					any_out[ray_id] = found_any ? 1 : 0;
+				} else {
+					rt_hit h;
+					if (best != RT_MISS) {
+						const uint32_t face = g.tri_face[best_tri];
+						h.t = (float)t_best;
+						h.prim = face;
+						h.tri = best_tri;
+						h.object = g.face_object[face];
+					} else {
+						h.t = __int_as_float(0x7f800000);
+						h.prim = RT_MISS;
+						h.tri = RT_MISS;
+						h.object = RT_MISS;
+					}
+					reinterpret_cast<uint4 *>(hits)[ray_id] = *reinterpret_cast<uint4 *>(&h);
+					if (t64) t64[ray_id] = best != RT_MISS ? t_best : (double)__int_as_float(0x7f800000);
+				}
+				active = false;
+			}
 		}
-		if (sp == 0) break;
-		sp--;
-		cur = LDS_STACK ? lds_stack[sp * kBlock + threadIdx.x] : scratch_stack[sp];
 	}
+}
 
-	if (ANY) {
-		any_out[i] = found_any ? 1 : 0;
-	} else {
-		rt_hit h;
-		if (best != RT_MISS) {
-			const uint32_t face = g.tri_face[best_tri];
-			h.t = (float)t_best;
-			h.prim = face;
-			h.tri = best_tri;
-			h.object = g.face_object[face];
-		} else {
-			h.t = __int_as_float(0x7f800000);
-			h.prim = RT_MISS;
-			h.tri = RT_MISS;
-			h.object = RT_MISS;
-		}
-		reinterpret_cast<uint4 *>(hits)[i] = *reinterpret_cast<uint4 *>(&h);
-		if (t64) t64[i] = best != RT_MISS ? t_best : (double)__int_as_float(0x7f800000);
-	}
+// grid: enough waves to fill the chip, each with a contiguous share of the rays
+struct TraceGrid { unsigned blocks; uint32_t rays_per_wave; };
+inline TraceGrid trace_grid(uint64_t n)
+{
+	const uint64_t waves_per_block = kBlock / 64;
+	const uint64_t max_blocks = 256ull * 4ull; // 256 CUs x 4 resident workgroups (register-limited: 4 waves per SIMD)
+	uint64_t blocks = (n + kBlock - 1) / kBlock;
+	if (blocks > max_blocks) blocks = max_blocks;
+	const uint64_t waves = blocks * waves_per_block;
+	TraceGrid tg;
+	tg.blocks = (unsigned)blocks;
+	tg.rays_per_wave = (uint32_t)((n + waves - 1) / waves);
+	return tg;
 }
 
 } // namespace
@@ -185,11 +263,11 @@ hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint6
 {
 	if (n == 0) return hipSuccess;
 	if (g.depth > (uint32_t)kScratchStack) return hipErrorInvalidValue;
-	const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
+	const TraceGrid tg = trace_grid(n);
 	if (g.depth <= (uint32_t)kLdsStack)
-		hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr);
+		hipLaunchKernelGGL((k_trace<true, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr, tg.rays_per_wave);
 	else
-		hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr);
+		hipLaunchKernelGGL((k_trace<false, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr, tg.rays_per_wave);
 	return hipGetLastError();
 }
 
@@ -197,11 +275,11 @@ hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t 
 {
 	if (n == 0) return hipSuccess;
 	if (g.depth > (uint32_t)kScratchStack) return hipErrorInvalidValue;
-	const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
+	const TraceGrid tg = trace_grid(n);
 	if (g.depth <= (uint32_t)kLdsStack)
-		hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out);
+		hipLaunchKernelGGL((k_trace<true, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out, tg.rays_per_wave);
 	else
-		hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out);
+		hipLaunchKernelGGL((k_trace<false, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out, tg.rays_per_wave);
 	return hipGetLastError();
 }
 
