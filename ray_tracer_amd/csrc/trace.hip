@@ -17,9 +17,19 @@ namespace mi355rt {
 
 namespace {
 
+// tunables (overridable at build time for experiments)
+#ifndef TRACE_LDS_STACK
+#define TRACE_LDS_STACK 32
+#endif
+#ifndef TRACE_REFILL_MIN
+#define TRACE_REFILL_MIN 16
+#endif
+#ifndef TRACE_WAVES_PER_SIMD
+#define TRACE_WAVES_PER_SIMD 4
+#endif
 constexpr int kBlock = 256;
-constexpr int kLdsStack = 32;     // entries per lane held in LDS: trees up to depth 33
-constexpr int kScratchStack = 96; // deeper trees (bounded by the builder)
+constexpr int kLdsStack = TRACE_LDS_STACK; // entries per lane held in LDS: trees up to that depth + 1
+constexpr int kScratchStack = 96;          // deeper trees (bounded by the builder)
 
 struct RayD {
 	double ox, oy, oz, dx, dy, dz, tmin;
@@ -68,7 +78,7 @@ __device__ __forceinline__ float next_up(float x) // smallest float > x for fini
 }
 
 constexpr int kDone = (int)0x80000000; // no leaf link has this value (first < 2^27 and count <= 16)
-constexpr int kRefillMin = 16;          // idle lanes in a wave before it takes new rays
+constexpr int kRefillMin = TRACE_REFILL_MIN; // idle lanes in a wave before it takes new rays
 
 // Persistent waves: each wave owns a contiguous range of rays and keeps its 64 lanes busy by handing
 // idle lanes the next rays of the range (no global work counter, so no same-address atomics).
@@ -76,7 +86,7 @@ constexpr int kRefillMin = 16;          // idle lanes in a wave before it takes 
 // keeps descending until it reaches a second leaf or runs out of nodes, so the expensive fp64 triangle
 // phase runs with most lanes holding work.
 template <bool LDS_STACK, bool ANY>
-__global__ void __launch_bounds__(kBlock) k_trace(DeviceGeom g, const rt_ray *__restrict__ rays, uint64_t n,
+__global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGeom g, const rt_ray *__restrict__ rays, uint64_t n,
                                                   rt_hit *__restrict__ hits, double *__restrict__ t64,
                                                   uint8_t *__restrict__ any_out, uint32_t rays_per_wave)
 {
@@ -84,9 +94,12 @@ __global__ void __launch_bounds__(kBlock) k_trace(DeviceGeom g, const rt_ray *__
 	int scratch_stack[LDS_STACK ? 1 : kScratchStack];
 	const int lane = threadIdx.x & 63;
 	const unsigned long long lt = (1ull << lane) - 1ull;
+	// wave w owns the 64-ray chunks w, w + W, w + 2W, ... (W = waves in the grid): neighbouring rays stay
+	// together in a wave, and every wave sees a sample of the whole batch, so the work per wave evens out
 	const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	uint64_t next = wave_id * rays_per_wave;
-	const uint64_t end = next + rays_per_wave < n ? next + rays_per_wave : n;
+	const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / 64);
+	uint64_t next = 0; // position in this wave's own sequence of rays
+	(void)rays_per_wave;
 
 	bool active = false;
 	uint64_t ray_id = 0;
@@ -99,11 +112,12 @@ __global__ void __launch_bounds__(kBlock) k_trace(DeviceGeom g, const rt_ray *__
 	for (;;) {
 		// ---- hand new rays to idle lanes
 		const unsigned long long idle = __ballot(!active);
-		if (idle != 0 && next < end) {
+		if (idle != 0 && ((next >> 6) * n_waves + wave_id) * 64 < n) {
 			const int nidle = __popcll(idle);
 			if (nidle >= kRefillMin) {
-				const uint64_t mine = next + (uint64_t)__popcll(idle & lt);
-				if (!active && mine < end) {
+				const uint64_t seq = next + (uint64_t)__popcll(idle & lt);
+				const uint64_t mine = ((seq >> 6) * n_waves + wave_id) * 64 + (seq & 63);
+				if (!active && mine < n) {
 					const float4 ra = reinterpret_cast<const float4 *>(rays)[2 * mine];
 					const float4 rb = reinterpret_cast<const float4 *>(rays)[2 * mine + 1];
 					ray_id = mine;
@@ -247,7 +261,7 @@ struct TraceGrid { unsigned blocks; uint32_t rays_per_wave; };
 inline TraceGrid trace_grid(uint64_t n)
 {
 	const uint64_t waves_per_block = kBlock / 64;
-	const uint64_t max_blocks = 256ull * 4ull; // 256 CUs x 4 resident workgroups (register-limited: 4 waves per SIMD)
+	const uint64_t max_blocks = 256ull * TRACE_WAVES_PER_SIMD; // 256 CUs x resident workgroups (one wave of each per SIMD)
 	uint64_t blocks = (n + kBlock - 1) / kBlock;
 	if (blocks > max_blocks) blocks = max_blocks;
 	const uint64_t waves = blocks * waves_per_block;
