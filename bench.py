@@ -156,7 +156,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
-    from ray_tracer_amd import capi, scenes, synth
+    from ray_tracer_amd import capi, parallel, scenes, synth
 
     def log(msg):
         if rank == 0:
@@ -181,6 +181,7 @@ def main():
     ctx.set_camera(cam)
     per_rank = (args.warmup + args.steps) * spp
     ns_total = per_rank * world
+    assert parallel.sample_range(rank, world, ns_total) == (rank * per_rank, per_rank)
     film = torch.zeros(nx * ny * capi.NBINS, dtype=torch.float32, device="cuda")
     ctx.render_begin(nx, ny, ns_total, 30, capi.ALG_MIS, 20261111, film.data_ptr())
     first = rank * per_rank
@@ -195,8 +196,7 @@ def main():
     for s in range(args.warmup, args.warmup + args.steps):
         ctx.render_pass(first + s * spp, spp)
     ctx.render_sync()
-    if world > 1:
-        dist.all_reduce(film)  # RCCL sum of the per-rank films over xGMI
+    parallel.reduce_film(film)  # one RCCL sum of the per-rank films over xGMI (no-op on one GPU)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

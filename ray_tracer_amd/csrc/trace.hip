@@ -24,6 +24,9 @@ namespace {
 #ifndef TRACE_REFILL_MIN
 #define TRACE_REFILL_MIN 16
 #endif
+#ifndef TRACE_NODE_MIN_LANES
+#define TRACE_NODE_MIN_LANES 0
+#endif
 #ifndef TRACE_WAVES_PER_SIMD
 #define TRACE_WAVES_PER_SIMD 4
 #endif
@@ -90,6 +93,10 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
                                                   rt_hit *__restrict__ hits, double *__restrict__ t64,
                                                   uint8_t *__restrict__ any_out, uint32_t rays_per_wave)
 {
+#ifdef TRACE_STATS
+	// diagnostic build only: wave-level loop trip counts and the lanes active in them, printed by wave 0 lanes
+	unsigned long long st_node_iter = 0, st_node_lanes = 0, st_leaf_iter = 0, st_leaf_lanes = 0, st_outer = 0, st_outer_lanes = 0;
+#endif
 	__shared__ int lds_stack[LDS_STACK ? kLdsStack * kBlock : 1];
 	int scratch_stack[LDS_STACK ? 1 : kScratchStack];
 	const int lane = threadIdx.x & 63;
@@ -137,9 +144,15 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 			}
 		}
 		if (__ballot(active) == 0) break;
+#ifdef TRACE_STATS
+		{ const unsigned long long m_ = __ballot(active); if (lane == __ffsll((long long)__ballot(true)) - 1) st_outer++; st_outer_lanes += active ? 1 : 0; (void)m_; }
+#endif
 		if (active) {
 			// ---- node phase: descend until this lane holds a parked leaf and stands on another, or is out of nodes
 			while (cur >= 0) {
+#ifdef TRACE_STATS
+				if (lane == __ffsll((long long)__ballot(true)) - 1) st_node_iter++; st_node_lanes++;
+#endif
 				const float4 q0 = g.nodes[4 * (size_t)cur], q1 = g.nodes[4 * (size_t)cur + 1];
 				const float4 q2 = g.nodes[4 * (size_t)cur + 2], q3 = g.nodes[4 * (size_t)cur + 3];
 				// child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
@@ -183,6 +196,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					}
 				}
 				if (__ballot(leaf == 0) == 0) break; // every lane still descending already holds a leaf
+				if (TRACE_NODE_MIN_LANES > 0 && __popcll(__ballot(true)) < TRACE_NODE_MIN_LANES) break; // too few lanes left
 			}
 			// ---- leaf phase: the parked leaf, then the leaf this lane stands on (if any)
 			if (leaf == 0 && cur < 0 && cur != kDone) {
@@ -194,6 +208,9 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				}
 			}
 			while (leaf != 0) {
+#ifdef TRACE_STATS
+				if (lane == __ffsll((long long)__ballot(true)) - 1) st_leaf_iter++; st_leaf_lanes++;
+#endif
 				const uint32_t c = (uint32_t)~leaf;
 				const uint32_t first = c & 0x07FFFFFFu, count = (c >> 27) + 1u;
 				RayD r;
@@ -248,12 +265,22 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 						h.object = RT_MISS;
 					}
 					reinterpret_cast<uint4 *>(hits)[ray_id] = *reinterpret_cast<uint4 *>(&h);
+#ifndef TRACE_STATS
 					if (t64) t64[ray_id] = best != RT_MISS ? t_best : (double)__int_as_float(0x7f800000);
+#endif
 				}
 				active = false;
 			}
 		}
 	}
+#ifdef TRACE_STATS
+	if (t64 && n > 1000000) { // every lane adds its own counts (t64 doubles as the stats sink in this build)
+		unsigned long long *sink = reinterpret_cast<unsigned long long *>(t64);
+		atomicAdd(&sink[0], st_node_iter); atomicAdd(&sink[1], st_node_lanes);
+		atomicAdd(&sink[2], st_leaf_iter); atomicAdd(&sink[3], st_leaf_lanes);
+		atomicAdd(&sink[4], st_outer); atomicAdd(&sink[5], st_outer_lanes);
+	}
+#endif
 }
 
 // grid: enough waves to fill the chip, each with a contiguous share of the rays
