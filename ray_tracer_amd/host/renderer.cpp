@@ -1,0 +1,111 @@
+#include "renderer.h"
+#include <algorithm>
+#include <cstdio>
+#include <iostream>
+#include <random>
+
+namespace mi355host {
+
+Renderer::Renderer(void) // renderer.cpp:12-16
+{
+	std::random_device rd;
+	seed = ((unsigned long long)rd() << 32) | rd();
+	if (rt_create(0, &gpu) != RT_OK) {
+		last_error = rt_last_error(nullptr);
+		std::fprintf(stderr, "%s\n", last_error.c_str());
+	}
+}
+
+Renderer::~Renderer() { rt_destroy(gpu); }
+
+void Renderer::Load(const char *objfilename) // renderer.cpp:18-22 (the parser's bool is ignored there too)
+{
+	obj_loader.Clear();
+	obj_loader.Load(objfilename);
+	std::vector<double> v, vt, vn;
+	std::vector<int64_t> corners;
+	std::vector<uint64_t> face_begin{0}, object_begin{0};
+	for (auto &p : obj_loader.v) { v.push_back(p[0]); v.push_back(p[1]); v.push_back(p[2]); }
+	for (auto &p : obj_loader.vt) { vt.push_back(p[0]); vt.push_back(p[1]); vt.push_back(p[2]); }
+	for (auto &p : obj_loader.vn) { vn.push_back(p[0]); vn.push_back(p[1]); vn.push_back(p[2]); }
+	for (auto *o : obj_loader.objects) {
+		for (auto &face : o->faces) {
+			for (auto &c : face) { corners.push_back(c[0]); corners.push_back(c[1]); corners.push_back(c[2]); }
+			face_begin.push_back(corners.size() / 3);
+		}
+		object_begin.push_back(face_begin.size() - 1);
+	}
+	rt_mesh m{v.data(), v.size() / 3, vt.data(), vt.size() / 3, vn.data(), vn.size() / 3, corners.data(),
+	          face_begin.data(), face_begin.size() - 1, object_begin.data(), (uint32_t)(object_begin.size() - 1)};
+	if (!gpu || rt_upload_mesh(gpu, &m) != RT_OK) {
+		last_error = gpu ? rt_last_error(gpu) : rt_last_error(nullptr);
+		std::fprintf(stderr, "%s\n", last_error.c_str());
+	}
+}
+
+bool Renderer::LoadMaterials(const std::map<std::string, std::shared_ptr<NodeMaterial>> &materials) // renderer.cpp:24-44
+{
+	std::vector<rt_material> recs;
+	for (size_t i = 0; i < obj_loader.objects.size(); i++) {
+		auto itr = materials.find(obj_loader.objects[i]->name);
+		if (itr == materials.end()) {
+			std::fprintf(stderr, "Material is unset for %s\n", obj_loader.objects[i]->name.c_str());
+			return false;
+		}
+		recs.push_back(itr->second->Record());
+	}
+	if (!gpu) return false;
+	int rc = rt_upload_materials(gpu, recs.data(), (uint32_t)recs.size());
+	if (rc != RT_OK) last_error = rt_last_error(gpu);
+	return rc == RT_OK; // RT_ERR_NO_LIGHTS: `light_objects.size() == 0` in the reference
+}
+
+void Renderer::Clear(void) // renderer.cpp:47-51
+{
+	obj_loader.Clear();
+	img_updated = false;
+}
+
+void Renderer::RenderImage(int nx, int ny, int ns, int spectral_samples, bool, bool print_progress) // renderer.cpp:54-160
+{
+	spectrum_img.assign((size_t)nx * ny, Spectrum());
+	preview_img.assign((size_t)nx * ny, dvec3());
+	rendering_runnnig = true;
+	rt_camera c = cam.Pod();
+	if (!gpu || rt_set_camera(gpu, &c) != RT_OK ||
+	    rt_render_begin(gpu, nx, ny, ns, spectral_samples, (int)algorithm_type, seed, nullptr) != RT_OK) {
+		last_error = gpu ? rt_last_error(gpu) : "no device";
+		std::fprintf(stderr, "%s\n", last_error.c_str());
+		rendering_runnnig = false;
+		return;
+	}
+	std::vector<double> prev((size_t)nx * ny * 3);
+	int s = 0;
+	while (s < ns) {
+		if (stop_rendering) break; // once per pass, renderer.cpp:70
+		int b = std::min(std::max(1, samples_per_pass), ns - s);
+		if (rt_render_pass(gpu, s, b) != RT_OK || rt_render_sync(gpu) != RT_OK) {
+			last_error = rt_last_error(gpu);
+			std::fprintf(stderr, "%s\n", last_error.c_str());
+			break;
+		}
+		s += b;
+		if (preview_img_flag || s == ns) { // renderer.cpp:124-143
+			rt_download_preview(gpu, s, prev.data());
+			for (size_t p = 0; p < (size_t)nx * ny; p++) preview_img[p] = dvec3(prev[3 * p], prev[3 * p + 1], prev[3 * p + 2]);
+			img_updated = true;
+		}
+		progress = static_cast<float>(s) / ns;
+		if (print_progress) std::cout << progress * 100.0 << "%" << std::endl;
+	}
+	std::vector<double> film((size_t)nx * ny * RT_NBINS);
+	rt_download_film(gpu, film.data());
+	for (size_t p = 0; p < (size_t)nx * ny; p++)
+		for (int k = 0; k < RT_NBINS; k++) spectrum_img[p].data[k] = film[p * RT_NBINS + k];
+	img_updated = true;
+	if (stop_rendering) stop_rendering = false;
+	rendering_runnnig = false;
+	if (print_progress) std::cout << "Completed" << std::endl;
+}
+
+} // namespace mi355host

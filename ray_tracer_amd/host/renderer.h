@@ -1,0 +1,48 @@
+// Host-side drop-in for the reference's `Renderer` (renderer.h:21-50): same public members, same error
+// behaviour, hot path on the MI355X through the C ABI of mi355rt.h.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "camera.h"
+#include "materialnode.h"
+#include "mi355rt.h"
+#include "obj.h"
+
+namespace mi355host {
+
+enum RenderingAlgorithm { Naive, NEE, MIS, NaiveBDPTType, MISBDPTType }; // renderer.h:12-18
+
+struct Spectrum { // spectrum.h:11-24, the part callers of Renderer touch
+	std::vector<double> data = std::vector<double>(RT_NBINS, 0.0);
+};
+
+class Renderer {
+public:
+	Renderer(void);
+	~Renderer();
+	void Load(const char *objfilename);
+	bool LoadMaterials(const std::map<std::string, std::shared_ptr<NodeMaterial>> &materials);
+	void Clear(void);
+	void RenderImage(int nx, int ny, int ns, int spectral_samples, bool enable_openmp, bool print_progress = false);
+	enum RenderingAlgorithm algorithm_type = NaiveBDPTType; // renderer.h:33
+	std::vector<Spectrum> spectrum_img;
+	std::vector<dvec3> preview_img;
+	obj obj_loader;
+	LensCamera cam;
+	bool preview_img_flag = true;
+	bool img_updated = false;
+	bool rendering_runnnig = false;
+	bool stop_rendering = false;
+	float progress = 0.0;
+	// additions: the reference seeds its generator from random_device; a fixed seed makes runs repeatable
+	unsigned long long seed;
+	int samples_per_pass = 1;
+	std::string last_error;
+
+private:
+	rt_context *gpu = nullptr;
+};
+
+} // namespace mi355host

@@ -1,0 +1,81 @@
+// Headless driver for the host-side Renderer: what the reference's `--cli` mode does (main.cpp:54-99) plus the
+// camera set-up the GUI performs (scene.cpp:866-867), with the linear film dumped for tests.
+//   rt_cli --obj scene.obj --materials materials.json --objmatmap map.json [--width W --height H --sample S]
+//          [--algorithm naive|nee|mis] [--seed N] [--spectral 30] [--film out.f64] [--ppm out.ppm] [--records out.f64]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include "renderer.h"
+
+using namespace mi355host;
+
+int main(int argc, char **argv)
+{
+	std::string objp, matp, mapp, film_out, ppm_out, rec_out, alg = "mis";
+	int w = 64, h = 64, ns = 4, spectral = 30;
+	unsigned long long seed = 1;
+	for (int i = 1; i + 1 < argc; i += 2) {
+		std::string k = argv[i], v = argv[i + 1];
+		if (k == "--obj") objp = v; else if (k == "--materials") matp = v; else if (k == "--objmatmap") mapp = v;
+		else if (k == "--width") w = std::atoi(v.c_str()); else if (k == "--height") h = std::atoi(v.c_str());
+		else if (k == "--sample") ns = std::atoi(v.c_str()); else if (k == "--algorithm") alg = v;
+		else if (k == "--seed") seed = std::strtoull(v.c_str(), nullptr, 10); else if (k == "--spectral") spectral = std::atoi(v.c_str());
+		else if (k == "--film") film_out = v; else if (k == "--ppm") ppm_out = v; else if (k == "--records") rec_out = v;
+		else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+	}
+	if (objp.empty() || matp.empty() || mapp.empty()) { std::fprintf(stderr, "need --obj --materials --objmatmap\n"); return 2; }
+	try {
+		auto named = LoadMaterialFile(matp);
+		auto omm = LoadObjMatMap(mapp);
+		std::map<std::string, std::shared_ptr<NodeMaterial>> by_object; // Scene::obj_materials, scene.cpp:302-315
+		for (auto &kv : omm) {
+			auto it = named.find(kv.second);
+			if (it != named.end()) by_object[kv.first] = it->second;
+		}
+		if (!rec_out.empty()) { // host logic only (no device needed): folded records in obj object order
+			obj parsed;
+			parsed.Load(objp.c_str());
+			std::ofstream f(rec_out, std::ios::binary);
+			for (auto *o : parsed.objects) {
+				rt_material m = by_object.at(o->name)->Record();
+				double head[2] = {(double)m.type, (double)m.light_flag};
+				f.write((const char *)head, sizeof(head));
+				f.write((const char *)m.a, sizeof(m.a));
+				f.write((const char *)m.b, sizeof(m.b));
+			}
+		}
+		Renderer r;
+		if (!r.last_error.empty()) return 3;
+		r.seed = seed;
+		r.Load(objp.c_str());
+		if (!r.LoadMaterials(by_object)) { std::fprintf(stderr, "LoadMaterials failed: %s\n", r.last_error.c_str()); return 4; }
+		r.cam.film_height = 0.024;
+		r.cam.film_width = 0.024 * w / h; // scene.cpp:668
+		r.cam.SetLens(60.0, 0.4);
+		r.cam.set_Camera(dvec3(0, 0, 3), dvec3(0, 0, 2), dvec3(0, 1, 0));
+		r.algorithm_type = alg == "naive" ? Naive : (alg == "nee" ? NEE : MIS);
+		r.preview_img_flag = false;
+		r.samples_per_pass = ns;
+		r.RenderImage(w, h, ns, spectral, true, false);
+		if (!r.last_error.empty()) return 5;
+		if (!film_out.empty()) {
+			std::ofstream f(film_out, std::ios::binary);
+			for (auto &s : r.spectrum_img) f.write((const char *)s.data.data(), sizeof(double) * RT_NBINS);
+		}
+		if (!ppm_out.empty()) { // main.cpp:84-98 / scene.cpp:835-851: 8-bit from the gamma-encoded preview
+			std::ofstream f(ppm_out);
+			f << "P3\n" << w << " " << h << "\n255\n";
+			for (int j = h - 1; j >= 0; j--)
+				for (int i = 0; i < w; i++) {
+					const dvec3 &c = r.preview_img[(size_t)i * h + j];
+					f << (int)(255.99 * c[0]) << " " << (int)(255.99 * c[1]) << " " << (int)(255.99 * c[2]) << "\n";
+				}
+		}
+	} catch (const std::exception &e) {
+		std::fprintf(stderr, "error: %s\n", e.what());
+		return 6;
+	}
+	return 0;
+}
