@@ -119,14 +119,14 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	if (!ctx->host.build(*mesh, err)) return set_err(ctx, RT_ERR_MESH, err);
 	BvhBuildOptions opt;
 	if (const char *s = std::getenv("MI355RT_MAX_LEAF")) opt.max_leaf = std::atoi(s);
-	build_bvh2(ctx->host, opt, ctx->bvh);
+	build_bvh(ctx->host, opt, ctx->bvh, ctx->wide);
 	const HostScene &hs = ctx->host;
 	const uint64_t nt = hs.n_tris;
 	// leaf-ordered fp64 triangle records
 	std::vector<double> tri_a(6 * std::max<uint64_t>(nt, 1), 0.0), tri_b(6 * std::max<uint64_t>(nt, 1), 0.0);
 	std::vector<uint32_t> tri_leaf(nt);
 	for (uint64_t li = 0; li < nt; li++) {
-		const uint32_t t = ctx->bvh.tri_index[li];
+		const uint32_t t = ctx->wide.tri_index[li];
 		tri_leaf[t] = (uint32_t)li;
 		const double *v0, *v1, *v2;
 		hs.tri_vertices(t, v0, v1, v2);
@@ -135,8 +135,8 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 		a[0] = v0[0]; a[1] = v0[1]; a[2] = v0[2]; a[3] = fn[0]; a[4] = fn[1]; a[5] = fn[2];
 		b[0] = v1[0]; b[1] = v1[1]; b[2] = v1[2]; b[3] = v2[0]; b[4] = v2[1]; b[5] = v2[2];
 	}
-	if (!dev_upload(ctx, ctx->d_nodes, ctx->bvh.nodes) || !dev_upload(ctx, ctx->d_tri_a, tri_a) || !dev_upload(ctx, ctx->d_tri_b, tri_b) ||
-	    !dev_upload(ctx, ctx->d_leaf_tri, ctx->bvh.tri_index) || !dev_upload(ctx, ctx->d_tri_face, hs.tri_face) ||
+	if (!dev_upload(ctx, ctx->d_nodes, ctx->wide.nodes) || !dev_upload(ctx, ctx->d_tri_a, tri_a) || !dev_upload(ctx, ctx->d_tri_b, tri_b) ||
+	    !dev_upload(ctx, ctx->d_leaf_tri, ctx->wide.tri_index) || !dev_upload(ctx, ctx->d_tri_face, hs.tri_face) ||
 	    !dev_upload(ctx, ctx->d_face_object, hs.face_object)) {
 		std::string keep = ctx->error;
 		ctx->free_geometry();
@@ -149,7 +149,7 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	ctx->geom.tri_face = (const uint32_t *)ctx->d_tri_face;
 	ctx->geom.face_object = (const uint32_t *)ctx->d_face_object;
 	ctx->geom.n_tris = (uint32_t)nt;
-	ctx->geom.depth = ctx->bvh.depth;
+	ctx->geom.depth = ctx->wide.depth;
 	hipError_t e = render_upload_scene(ctx->render, hs, tri_leaf, ctx->geom.tri_face, ctx->geom.face_object, ctx->stream, err);
 	if (e != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	ctx->has_mesh = true;
@@ -196,6 +196,7 @@ int rt_clear(rt_context *ctx)
 	ctx->has_materials = false;
 	ctx->host = HostScene();
 	ctx->bvh = Bvh2();
+	ctx->wide = BvhWide();
 	return RT_OK;
 }
 

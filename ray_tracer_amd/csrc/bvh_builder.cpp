@@ -193,15 +193,136 @@ struct Flattener {
 	}
 };
 
+// Collapse to 8-wide nodes and quantise.
+struct WideFlattener {
+	const Builder &b;
+	BvhWide &out;
+
+	static int floor_log2_cells(double extent) // smallest e with 2^e * 255 >= extent
+	{
+		if (!(extent > 0.0)) return -126;
+		int e = (int)std::ceil(std::log2(extent / 255.0));
+		while (std::ldexp(1.0, e) * 255.0 < extent) e++;
+		if (e < -126) e = -126;
+		if (e > 127) e = 127;
+		return e;
+	}
+
+	void emit(int32_t t, uint32_t me, uint32_t depth)
+	{
+		if (depth > out.depth) out.depth = depth;
+		// ---- pick up to 8 children: open the interior child with the largest area until full
+		int32_t kids[8];
+		int nk = 0;
+		if (b.temp[t].left < 0) kids[nk++] = t; // the whole tree is one leaf
+		else { kids[nk++] = b.temp[t].left; kids[nk++] = b.temp[t].right; }
+		while (nk < 8) {
+			int best = -1;
+			float best_area = -1.0f;
+			for (int i = 0; i < nk; i++)
+				if (b.temp[kids[i]].left >= 0 && b.temp[kids[i]].box.half_area() > best_area) { best_area = b.temp[kids[i]].box.half_area(); best = i; }
+			if (best < 0) break;
+			const int32_t open = kids[best];
+			kids[best] = b.temp[open].left;
+			kids[nk++] = b.temp[open].right;
+		}
+		// ---- node box and cell sizes
+		Box box;
+		box.reset();
+		for (int i = 0; i < nk; i++) box.grow(b.temp[kids[i]].box);
+		WideNode nd;
+		std::memset(&nd, 0, sizeof(nd));
+		double scale[3];
+		for (int a = 0; a < 3; a++) {
+			nd.org[a] = box.lo[a];
+			int e = floor_log2_cells((double)box.hi[a] - (double)box.lo[a]);
+			nd.e[a] = (uint8_t)(e + 127);
+			scale[a] = std::ldexp(1.0, e);
+		}
+		// ---- slots: the octant of the child's centre relative to the node's centre, nearest free slot otherwise
+		int slot_of[8], child_in_slot[8];
+		for (int sl = 0; sl < 8; sl++) child_in_slot[sl] = -1;
+		int order[8];
+		float dist[8];
+		for (int i = 0; i < nk; i++) {
+			order[i] = i;
+			float dsum = 0.0f;
+			for (int a = 0; a < 3; a++) {
+				float c = 0.5f * (b.temp[kids[i]].box.lo[a] + b.temp[kids[i]].box.hi[a]), m = 0.5f * (box.lo[a] + box.hi[a]);
+				dsum += std::fabs(c - m);
+			}
+			dist[i] = dsum;
+		}
+		std::sort(order, order + nk, [&](int x, int y) { return dist[x] > dist[y] || (dist[x] == dist[y] && x < y); });
+		for (int oi = 0; oi < nk; oi++) {
+			const int i = order[oi];
+			int want = 0;
+			for (int a = 0; a < 3; a++) {
+				float c = 0.5f * (b.temp[kids[i]].box.lo[a] + b.temp[kids[i]].box.hi[a]), m = 0.5f * (box.lo[a] + box.hi[a]);
+				if (c > m) want |= 1 << a;
+			}
+			int best_slot = -1, best_d = 99;
+			for (int sl = 0; sl < 8; sl++) {
+				if (child_in_slot[sl] >= 0) continue;
+				int d = __builtin_popcount((unsigned)(sl ^ want));
+				if (d < best_d) { best_d = d; best_slot = sl; }
+			}
+			slot_of[i] = best_slot;
+			child_in_slot[best_slot] = i;
+		}
+		// ---- quantise, collect interior children and leaf triangles in slot order
+		for (int a = 0; a < 3; a++)
+			for (int sl = 0; sl < 8; sl++) { nd.qlo[a][sl] = 255; nd.qhi[a][sl] = 0; }
+		int n_interior = 0;
+		nd.tri_base = (uint32_t)out.tri_index.size();
+		for (int sl = 0; sl < 8; sl++) {
+			const int i = child_in_slot[sl];
+			if (i < 0) continue;
+			const TempNode &c = b.temp[kids[i]];
+			for (int a = 0; a < 3; a++) {
+				double lo = std::floor(((double)c.box.lo[a] - (double)nd.org[a]) / scale[a]);
+				double hi = std::ceil(((double)c.box.hi[a] - (double)nd.org[a]) / scale[a]);
+				lo = std::max(0.0, std::min(255.0, lo));
+				hi = std::max(0.0, std::min(255.0, hi));
+				// the cells must cover the child's box (they do by construction; the node box covers it)
+				while ((double)nd.org[a] + lo * scale[a] > (double)c.box.lo[a] && lo > 0.0) lo -= 1.0;
+				while ((double)nd.org[a] + hi * scale[a] < (double)c.box.hi[a] && hi < 255.0) hi += 1.0;
+				nd.qlo[a][sl] = (uint8_t)lo;
+				nd.qhi[a][sl] = (uint8_t)hi;
+			}
+			if (c.left >= 0) {
+				nd.imask |= (uint8_t)(1u << sl);
+				n_interior++;
+			} else {
+				const uint32_t off = (uint32_t)out.tri_index.size() - nd.tri_base;
+				nd.meta[sl] = (uint8_t)((c.count << 5) | off);
+				for (uint32_t k = 0; k < c.count; k++) out.tri_index.push_back(b.idx[c.first + k]);
+			}
+		}
+		nd.child_base = (uint32_t)out.nodes.size();
+		out.nodes.resize(out.nodes.size() + n_interior);
+		out.nodes[me] = nd;
+		uint32_t rel = 0;
+		for (int sl = 0; sl < 8; sl++) {
+			const int i = child_in_slot[sl];
+			if (i < 0 || b.temp[kids[i]].left < 0) continue;
+			emit(kids[i], nd.child_base + rel, depth + 1);
+			rel++;
+		}
+		(void)slot_of;
+	}
+};
+
 } // namespace
 
-void build_bvh2(const HostScene &scene, const BvhBuildOptions &opt_in, Bvh2 &out)
+void build_bvh(const HostScene &scene, const BvhBuildOptions &opt_in, Bvh2 &out, BvhWide &wide)
 {
 	auto t_start = std::chrono::steady_clock::now();
 	BvhBuildOptions opt = opt_in;
-	opt.max_leaf = std::max(1, std::min(opt.max_leaf, 16));
+	opt.max_leaf = std::max(1, std::min(opt.max_leaf, 4)); // a wide node addresses at most 32 triangles: 8 leaves x 4
 	opt.bins = std::max(4, std::min(opt.bins, 256));
 	out = Bvh2();
+	wide = BvhWide();
 	const uint64_t n = scene.n_tris;
 	const float inf = std::numeric_limits<float>::infinity();
 	auto empty_child = [&](rt_bvh2_node &nd, int which) {
@@ -216,6 +337,11 @@ void build_bvh2(const HostScene &scene, const BvhBuildOptions &opt_in, Bvh2 &out
 		root.child0 = root.child1 = make_leaf_link(0, 1);
 		out.nodes.push_back(root);
 		out.depth = 1;
+		WideNode w;
+		std::memset(&w, 0, sizeof(w));
+		for (int a = 0; a < 3; a++) { w.e[a] = 1; for (int sl = 0; sl < 8; sl++) { w.qlo[a][sl] = 255; w.qhi[a][sl] = 0; } }
+		wide.nodes.push_back(w);
+		wide.depth = 1;
 		return;
 	}
 	Builder b(opt);
@@ -259,6 +385,11 @@ void build_bvh2(const HostScene &scene, const BvhBuildOptions &opt_in, Bvh2 &out
 	} else {
 		fl.emit((int32_t)root, 0);
 	}
+	wide.nodes.reserve(n / 2 + 16);
+	wide.tri_index.reserve(n);
+	wide.nodes.resize(1);
+	WideFlattener wf{b, wide};
+	wf.emit((int32_t)root, 0, 1);
 	out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 }
 

@@ -27,7 +27,39 @@ struct BvhBuildOptions {
 	int threads = 0;        // 0 = hardware concurrency (capped at 32)
 };
 
-void build_bvh2(const HostScene &scene, const BvhBuildOptions &opt, Bvh2 &out);
+// The tree the traversal kernel walks: the BVH2 collapsed to 8 children per node, child boxes quantised to
+// 8 bits per coordinate inside the node's own box (always rounded outward), 128 bytes = one L2 line per node.
+//   bytes  0..11  org[3]      node box minimum (float)
+//         12..14  e[3]        biased exponents: cell size on axis a is 2^(e[a]-127)
+//         15      imask       bit i: child i is an interior node
+//         16..19  child_base  index of the first interior child; interior children are consecutive in slot order
+//         20..23  tri_base    first triangle (leaf order) of this node's leaf children, consecutive in slot order
+//         24..31  meta[8]     leaf child: (count << 5) | offset from tri_base; otherwise 0
+//         32..55  qlo[3][8]   per axis, per child: lower bound in cells
+//         56..79  qhi[3][8]   per axis, per child: upper bound in cells  (empty slot: qlo 255 > qhi 0)
+// Children sit in the slot whose three bits say on which side of the node's centre they lie, so that
+// slot XOR ray-octant orders them front to back without sorting.
+struct WideNode {
+	float org[3];
+	uint8_t e[3];
+	uint8_t imask;
+	uint32_t child_base;
+	uint32_t tri_base;
+	uint8_t meta[8];
+	uint8_t qlo[3][8];
+	uint8_t qhi[3][8];
+	uint8_t pad[48];
+};
+static_assert(sizeof(WideNode) == 128, "one node per 128-byte line");
+
+struct BvhWide {
+	std::vector<WideNode> nodes;     // node 0 = root
+	std::vector<uint32_t> tri_index; // leaf order -> fan triangle id
+	uint32_t depth = 0;              // nodes on the longest root-to-leaf path
+};
+
+// builds the binary tree once and flattens it twice (out2 for introspection / work counting, wide for the device)
+void build_bvh(const HostScene &scene, const BvhBuildOptions &opt, Bvh2 &out2, BvhWide &wide);
 
 inline int32_t make_leaf_link(uint32_t first, uint32_t count) { return ~(int32_t)(((count - 1u) << 27) | first); }
 

@@ -16,7 +16,8 @@ struct rt_context {
 	mutable std::string error;
 
 	mi355rt::HostScene host;
-	mi355rt::Bvh2 bvh;
+	mi355rt::Bvh2 bvh;     // binary tree, host only: introspection and work counting
+	mi355rt::BvhWide wide; // the tree the device walks
 	bool has_mesh = false, has_materials = false, has_camera = false;
 
 	// geometry in HBM

@@ -7,7 +7,7 @@
 namespace mi355rt {
 
 // Geometry the traversal kernels read.
-//   nodes     rt_bvh2_node as 4 x float4: {lo0.xyz,hi0.x} {hi0.yz,lo1.xy} {lo1.z,hi1.xyz} {child0,child1,-,-}
+//   nodes     WideNode (bvh_builder.h), 128 bytes each, read as 5 x uint4 (80 bytes are used)
 //   tri_a     per leaf-ordered triangle, 6 doubles: v0.xyz, face_normal.xyz   (the plane; enough to compute t)
 //   tri_b     per leaf-ordered triangle, 6 doubles: v1.xyz, v2.xyz            (read only when t is in range)
 //   leaf_tri  leaf order -> fan triangle id

@@ -19,7 +19,7 @@ namespace {
 
 // tunables (overridable at build time for experiments)
 #ifndef TRACE_LDS_STACK
-#define TRACE_LDS_STACK 32
+#define TRACE_LDS_STACK 16
 #endif
 #ifndef TRACE_REFILL_MIN
 #define TRACE_REFILL_MIN 16
@@ -31,7 +31,7 @@ namespace {
 #define TRACE_WAVES_PER_SIMD 4
 #endif
 constexpr int kBlock = 256;
-constexpr int kLdsStack = TRACE_LDS_STACK; // entries per lane held in LDS: trees up to that depth + 1
+constexpr int kLdsStack = TRACE_LDS_STACK; // stack entries (8 bytes) per lane held in LDS: one per tree level
 constexpr int kScratchStack = 96;          // deeper trees (bounded by the builder)
 
 struct RayD {
@@ -80,41 +80,56 @@ __device__ __forceinline__ float next_up(float x) // smallest float > x for fini
 	return __int_as_float(i);
 }
 
-constexpr int kDone = (int)0x80000000; // no leaf link has this value (first < 2^27 and count <= 16)
 constexpr int kRefillMin = TRACE_REFILL_MIN; // idle lanes in a wave before it takes new rays
 
-// Persistent waves: each wave owns a contiguous range of rays and keeps its 64 lanes busy by handing
-// idle lanes the next rays of the range (no global work counter, so no same-address atomics).
-// Traversal is "while-while" with one postponed leaf per lane: a lane that reaches a leaf parks it and
-// keeps descending until it reaches a second leaf or runs out of nodes, so the expensive fp64 triangle
-// phase runs with most lanes holding work.
+// bit p of the result = bit (p ^ oct) of x, for 8-bit x: children sit in slots whose bits say on which side of
+// the node centre they lie; after this permutation the lowest set bit is the child nearest along the ray
+__device__ __forceinline__ uint32_t permute_by_octant(uint32_t x, uint32_t oct)
+{
+	uint32_t s1 = ((x & 0x55u) << 1) | ((x >> 1) & 0x55u);
+	x = (oct & 1u) ? s1 : x;
+	uint32_t s2 = ((x & 0x33u) << 2) | ((x >> 2) & 0x33u);
+	x = (oct & 2u) ? s2 : x;
+	uint32_t s4 = ((x & 0x0Fu) << 4) | ((x >> 4) & 0x0Fu);
+	x = (oct & 4u) ? s4 : x;
+	return x;
+}
+
+__device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); } // v_cvt_f32_ubyteK
+
+// Persistent waves: each wave owns an interleaved share of the 64-ray chunks and keeps its 64 lanes busy by
+// handing idle lanes the next rays of its share (no global work counter, so no same-address atomics).
+//
+// The tree is 8 wide with quantised child boxes, one 128-byte line per node.  A lane's traversal state is a
+// "group": the children of one node that are still to be visited (base index + a bit mask already ordered
+// front to back), so the stack holds at most one entry per tree level.  Leaf children that the ray's box test
+// hits are kept as a parked group (triangle base + per-child counts + hit mask) while the lane goes on
+// descending; the fp64 triangle phase runs when a lane holds two parked groups or has run out of nodes,
+// so that it runs with most lanes holding work.
 template <bool LDS_STACK, bool ANY>
 __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGeom g, const rt_ray *__restrict__ rays, uint64_t n,
                                                   rt_hit *__restrict__ hits, double *__restrict__ t64,
-                                                  uint8_t *__restrict__ any_out, uint32_t rays_per_wave)
+                                                  uint8_t *__restrict__ any_out)
 {
-#ifdef TRACE_STATS
-	// diagnostic build only: wave-level loop trip counts and the lanes active in them, printed by wave 0 lanes
-	unsigned long long st_node_iter = 0, st_node_lanes = 0, st_leaf_iter = 0, st_leaf_lanes = 0, st_outer = 0, st_outer_lanes = 0;
-#endif
-	__shared__ int lds_stack[LDS_STACK ? kLdsStack * kBlock : 1];
-	int scratch_stack[LDS_STACK ? 1 : kScratchStack];
+	__shared__ uint32_t lds_base[LDS_STACK ? kLdsStack * kBlock : 1];
+	__shared__ uint32_t lds_mask[LDS_STACK ? kLdsStack * kBlock : 1];
+	uint32_t scr_base[LDS_STACK ? 1 : kScratchStack], scr_mask[LDS_STACK ? 1 : kScratchStack];
 	const int lane = threadIdx.x & 63;
 	const unsigned long long lt = (1ull << lane) - 1ull;
-	// wave w owns the 64-ray chunks w, w + W, w + 2W, ... (W = waves in the grid): neighbouring rays stay
-	// together in a wave, and every wave sees a sample of the whole batch, so the work per wave evens out
 	const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / 64);
 	uint64_t next = 0; // position in this wave's own sequence of rays
-	(void)rays_per_wave;
 
 	bool active = false;
 	uint64_t ray_id = 0;
 	float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tmin_f = 0, tfar_f = 0;
 	double t_best = 0.0;
-	uint32_t best = RT_MISS, best_tri = RT_MISS;
+	uint32_t best = RT_MISS, best_tri = RT_MISS, oct = 0;
 	bool found_any = false;
-	int sp = 0, cur = kDone, leaf = 0;
+	int sp = 0;
+	uint32_t g_base = 0, g_mask = 0;               // current group: low byte = pending children (ordered), next byte = imask
+	uint32_t l0_base = 0, l0_m0 = 0, l0_m1 = 0, l0_hits = 0; // parked leaf group 0: tri_base, meta[0..3], meta[4..7], hit children
+	uint32_t l1_base = 0, l1_m0 = 0, l1_m1 = 0, l1_hits = 0; // parked leaf group 1
 
 	for (;;) {
 		// ---- hand new rays to idle lanes
@@ -131,123 +146,128 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					ox = ra.x; oy = ra.y; oz = ra.z; tmin_f = ra.w;
 					dx = rb.x; dy = rb.y; dz = rb.z; tfar_f = rb.w;
 					ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+					oct = (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
 					t_best = isinf(rb.w) ? DBL_MAX : (double)rb.w; // t_max; shrinks to the closest accepted t
 					best = RT_MISS;
 					best_tri = RT_MISS;
 					found_any = false;
 					sp = 0;
-					cur = 0;
-					leaf = 0;
+					g_base = 0;                       // the root as a one-child group
+					g_mask = (1u << oct) | (1u << 8); // slot 0 lands on position 0 ^ oct
+					l0_hits = 0;
+					l1_hits = 0;
 					active = true;
 				}
 				next += (uint64_t)nidle;
 			}
 		}
 		if (__ballot(active) == 0) break;
-#ifdef TRACE_STATS
-		{ const unsigned long long m_ = __ballot(active); if (lane == __ffsll((long long)__ballot(true)) - 1) st_outer++; st_outer_lanes += active ? 1 : 0; (void)m_; }
-#endif
 		if (active) {
-			// ---- node phase: descend until this lane holds a parked leaf and stands on another, or is out of nodes
-			while (cur >= 0) {
-#ifdef TRACE_STATS
-				if (lane == __ffsll((long long)__ballot(true)) - 1) st_node_iter++; st_node_lanes++;
-#endif
-				const float4 q0 = g.nodes[4 * (size_t)cur], q1 = g.nodes[4 * (size_t)cur + 1];
-				const float4 q2 = g.nodes[4 * (size_t)cur + 2], q3 = g.nodes[4 * (size_t)cur + 3];
-				// child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
-				float a0 = (q0.x - ox) * ix, b0 = (q0.w - ox) * ix;
-				float a1 = (q0.y - oy) * iy, b1 = (q1.x - oy) * iy;
-				float a2 = (q0.z - oz) * iz, b2 = (q1.y - oz) * iz;
-				const float n0 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), tmin_f));
-				const float f0 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), tfar_f));
-				a0 = (q1.z - ox) * ix; b0 = (q2.y - ox) * ix;
-				a1 = (q1.w - oy) * iy; b1 = (q2.z - oy) * iy;
-				a2 = (q2.x - oz) * iz; b2 = (q2.w - oz) * iz;
-				const float n1 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), tmin_f));
-				const float f1 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), tfar_f));
-				// slack: each slab distance carries <= 3 roundings (2^-24 each)
-				const bool h0 = n0 <= fmaf(fabsf(f0), 1e-6f, f0);
-				const bool h1 = n1 <= fmaf(fabsf(f1), 1e-6f, f1);
-				const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-				if (h0 && h1) {
-					const bool swap = n1 < n0;
-					const int farc = swap ? c0 : c1;
-					if (LDS_STACK) lds_stack[sp * kBlock + threadIdx.x] = farc;
-					else scratch_stack[sp] = farc;
+			// ---- node phase
+			for (;;) {
+				if ((g_mask & 0xFFu) == 0) {
+					if (sp == 0) break; // out of nodes
+					sp--;
+					g_base = LDS_STACK ? lds_base[sp * kBlock + threadIdx.x] : scr_base[sp];
+					g_mask = LDS_STACK ? lds_mask[sp * kBlock + threadIdx.x] : scr_mask[sp];
+				}
+				if (l1_hits != 0) break; // two parked leaf groups: wait for the triangle phase
+				// nearest pending child of the group
+				const uint32_t pos = (uint32_t)__ffs((int)(g_mask & 0xFFu)) - 1u;
+				g_mask &= ~(1u << pos);
+				const uint32_t slot = pos ^ oct;
+				const uint32_t rel = (uint32_t)__popc((g_mask >> 8) & ((1u << slot) - 1u));
+				const uint32_t node = g_base + rel;
+				if ((g_mask & 0xFFu) != 0) { // siblings left: keep the group for later
+					if (LDS_STACK) { lds_base[sp * kBlock + threadIdx.x] = g_base; lds_mask[sp * kBlock + threadIdx.x] = g_mask; }
+					else { scr_base[sp] = g_base; scr_mask[sp] = g_mask; }
 					sp++;
-					cur = swap ? c1 : c0;
-				} else if (h0) {
-					cur = c0;
-				} else if (h1) {
-					cur = c1;
-				} else if (sp == 0) {
-					cur = kDone;
-				} else {
-					sp--;
-					cur = LDS_STACK ? lds_stack[sp * kBlock + threadIdx.x] : scratch_stack[sp];
 				}
-				if (cur < 0 && cur != kDone && leaf == 0) { // park the first leaf and keep going
-					leaf = cur;
-					if (sp == 0) cur = kDone;
-					else {
-						sp--;
-						cur = LDS_STACK ? lds_stack[sp * kBlock + threadIdx.x] : scratch_stack[sp];
-					}
+				const uint4 *np = reinterpret_cast<const uint4 *>(g.nodes) + 8 * (size_t)node;
+				const uint4 h0 = np[0], h1 = np[1], q0 = np[2], q1 = np[3], q2 = np[4];
+				// h0 = org.xyz, e|imask ; h1 = child_base, tri_base, meta[0..3], meta[4..7]
+				// q0 = qlo.x[0..7], qlo.y[0..7] ; q1 = qlo.z[0..7], qhi.x[0..7] ; q2 = qhi.y[0..7], qhi.z[0..7]
+				const float sx = __uint_as_float((h0.w & 0xFFu) << 23), sy = __uint_as_float(((h0.w >> 8) & 0xFFu) << 23);
+				const float sz = __uint_as_float(((h0.w >> 16) & 0xFFu) << 23);
+				const uint32_t imask = h0.w >> 24;
+				// t(q) = q * (cell * inv) + (org - o) * inv.  cell * inv is exact (power of two); the second term
+				// carries two roundings and can cancel against the first, so it is widened by 2^-22 of itself
+				const float ax = (__uint_as_float(h0.x) - ox) * ix, ay = (__uint_as_float(h0.y) - oy) * iy, az = (__uint_as_float(h0.z) - oz) * iz;
+				const float kx = sx * ix, ky = sy * iy, kz = sz * iz;
+				const float wid = 2.384185791015625e-7f; // 2^-22
+				const float axn = fmaf(-wid, fabsf(ax), ax), axf = fmaf(wid, fabsf(ax), ax);
+				const float ayn = fmaf(-wid, fabsf(ay), ay), ayf = fmaf(wid, fabsf(ay), ay);
+				const float azn = fmaf(-wid, fabsf(az), az), azf = fmaf(wid, fabsf(az), az);
+				// entry plane is the lower bound when the direction component is positive, else the upper bound
+				const bool px = (oct & 1u) == 0, py = (oct & 2u) == 0, pz = (oct & 4u) == 0;
+				const uint32_t nx0 = px ? q0.x : q1.z, nx1 = px ? q0.y : q1.w, fx0 = px ? q1.z : q0.x, fx1 = px ? q1.w : q0.y;
+				const uint32_t ny0 = py ? q0.z : q2.x, ny1 = py ? q0.w : q2.y, fy0 = py ? q2.x : q0.z, fy1 = py ? q2.y : q0.w;
+				const uint32_t nz0 = pz ? q1.x : q2.z, nz1 = pz ? q1.y : q2.w, fz0 = pz ? q2.z : q1.x, fz1 = pz ? q2.w : q1.y;
+				uint32_t hitmask = 0;
+#pragma unroll
+				for (int j = 0; j < 8; j++) {
+					const int k = j & 3;
+					const float tnx = fmaf(byte_to_float(j < 4 ? nx0 : nx1, k), kx, axn);
+					const float tny = fmaf(byte_to_float(j < 4 ? ny0 : ny1, k), ky, ayn);
+					const float tnz = fmaf(byte_to_float(j < 4 ? nz0 : nz1, k), kz, azn);
+					const float tfx = fmaf(byte_to_float(j < 4 ? fx0 : fx1, k), kx, axf);
+					const float tfy = fmaf(byte_to_float(j < 4 ? fy0 : fy1, k), ky, ayf);
+					const float tfz = fmaf(byte_to_float(j < 4 ? fz0 : fz1, k), kz, azf);
+					const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin_f));
+					const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tfar_f));
+					// relative slack for the fma roundings; an empty slot has qlo 255 > qhi 0 on every axis and never passes
+					if (tn <= fmaf(fabsf(tf), 1e-6f, tf)) hitmask |= 1u << j;
 				}
-				if (__ballot(leaf == 0) == 0) break; // every lane still descending already holds a leaf
-				if (TRACE_NODE_MIN_LANES > 0 && __popcll(__ballot(true)) < TRACE_NODE_MIN_LANES) break; // too few lanes left
+				// an empty slot that passes (possible only for rays with zero direction components, where distances
+				// turn into inf/NaN and drop out of min/max) is harmless: its imask bit is 0 and its meta count is 0
+				const uint32_t leaf_hits = hitmask & ~imask;
+				g_base = h1.x;
+				g_mask = permute_by_octant(hitmask & imask, oct) | (imask << 8);
+				if (leaf_hits != 0) {
+					if (l0_hits == 0) { l0_base = h1.y; l0_m0 = h1.z; l0_m1 = h1.w; l0_hits = leaf_hits; }
+					else { l1_base = h1.y; l1_m0 = h1.z; l1_m1 = h1.w; l1_hits = leaf_hits; }
+				}
+				if (__ballot(l0_hits == 0) == 0) break; // every lane still descending already holds triangles to test
 			}
-			// ---- leaf phase: the parked leaf, then the leaf this lane stands on (if any)
-			if (leaf == 0 && cur < 0 && cur != kDone) {
-				leaf = cur;
-				if (sp == 0) cur = kDone;
-				else {
-					sp--;
-					cur = LDS_STACK ? lds_stack[sp * kBlock + threadIdx.x] : scratch_stack[sp];
-				}
-			}
-			while (leaf != 0) {
-#ifdef TRACE_STATS
-				if (lane == __ffsll((long long)__ballot(true)) - 1) st_leaf_iter++; st_leaf_lanes++;
-#endif
-				const uint32_t c = (uint32_t)~leaf;
-				const uint32_t first = c & 0x07FFFFFFu, count = (c >> 27) + 1u;
+			// ---- triangle phase: both parked groups
+			if (l0_hits != 0) {
 				RayD r;
 				r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz; r.tmin = tmin_f;
-				for (uint32_t k = 0; k < count; k++) {
-					const uint32_t li = first + k;
-					const double2 a0 = g.tri_a[3 * (size_t)li], a1 = g.tri_a[3 * (size_t)li + 1], a2 = g.tri_a[3 * (size_t)li + 2];
-					// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz)
-					const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
-					if (!(t >= r.tmin && t <= t_best)) continue;
-					const double2 b0 = g.tri_b[3 * (size_t)li], b1 = g.tri_b[3 * (size_t)li + 1], b2 = g.tri_b[3 * (size_t)li + 2];
-					// b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
-					if (!inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) continue;
-					if (ANY) { found_any = true; break; }
-					const uint32_t tri = g.leaf_tri[li];
-					if (t < t_best || best == RT_MISS || tri < best_tri) { // ties in t: lowest fan triangle
-						t_best = t;
-						best = li;
-						best_tri = tri;
-						float tf = (float)t;
-						if ((double)tf < t) tf = next_up(tf);
-						tfar_f = tf;
+				while (l0_hits != 0) {
+					const uint32_t c = (uint32_t)__ffs((int)l0_hits) - 1u;
+					l0_hits &= l0_hits - 1u;
+					const uint32_t meta = ((c < 4 ? l0_m0 : l0_m1) >> (8 * (c & 3))) & 0xFFu;
+					const uint32_t first = l0_base + (meta & 31u), count = meta >> 5;
+					for (uint32_t k = 0; k < count; k++) {
+						const uint32_t li = first + k;
+						const double2 a0 = g.tri_a[3 * (size_t)li], a1 = g.tri_a[3 * (size_t)li + 1], a2 = g.tri_a[3 * (size_t)li + 2];
+						// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz)
+						const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
+						if (!(t >= r.tmin && t <= t_best)) continue;
+						const double2 b0 = g.tri_b[3 * (size_t)li], b1 = g.tri_b[3 * (size_t)li + 1], b2 = g.tri_b[3 * (size_t)li + 2];
+						// b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
+						if (!inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) continue;
+						if (ANY) { found_any = true; break; }
+						const uint32_t tri = g.leaf_tri[li];
+						if (t < t_best || best == RT_MISS || tri < best_tri) { // ties in t: lowest fan triangle
+							t_best = t;
+							best = li;
+							best_tri = tri;
+							float tf = (float)t;
+							if ((double)tf < t) tf = next_up(tf);
+							tfar_f = tf;
+						}
 					}
-				}
-				leaf = 0;
-				if (ANY && found_any) { cur = kDone; break; }
-				if (cur < 0 && cur != kDone) {
-					leaf = cur;
-					if (sp == 0) cur = kDone;
-					else {
-						sp--;
-						cur = LDS_STACK ? lds_stack[sp * kBlock + threadIdx.x] : scratch_stack[sp];
+					if (ANY && found_any) break;
+					if (l0_hits == 0 && l1_hits != 0) { // second group takes the first one's place
+						l0_base = l1_base; l0_m0 = l1_m0; l0_m1 = l1_m1; l0_hits = l1_hits;
+						l1_hits = 0;
 					}
 				}
 			}
 			// ---- finished: write the result, free the lane
-			if (cur == kDone) {
+			const bool out_of_nodes = (g_mask & 0xFFu) == 0 && sp == 0;
+			if ((ANY && found_any) || (out_of_nodes && l0_hits == 0 && l1_hits == 0)) {
 				if (ANY) {
 					any_out[ray_id] = found_any ? 1 : 0;
 				} else {
@@ -265,22 +285,14 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 						h.object = RT_MISS;
 					}
 					reinterpret_cast<uint4 *>(hits)[ray_id] = *reinterpret_cast<uint4 *>(&h);
-#ifndef TRACE_STATS
 					if (t64) t64[ray_id] = best != RT_MISS ? t_best : (double)__int_as_float(0x7f800000);
-#endif
 				}
+				l0_hits = 0;
+				l1_hits = 0;
 				active = false;
 			}
 		}
 	}
-#ifdef TRACE_STATS
-	if (t64 && n > 1000000) { // every lane adds its own counts (t64 doubles as the stats sink in this build)
-		unsigned long long *sink = reinterpret_cast<unsigned long long *>(t64);
-		atomicAdd(&sink[0], st_node_iter); atomicAdd(&sink[1], st_node_lanes);
-		atomicAdd(&sink[2], st_leaf_iter); atomicAdd(&sink[3], st_leaf_lanes);
-		atomicAdd(&sink[4], st_outer); atomicAdd(&sink[5], st_outer_lanes);
-	}
-#endif
 }
 
 // grid: enough waves to fill the chip, each with a contiguous share of the rays
@@ -306,9 +318,9 @@ hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint6
 	if (g.depth > (uint32_t)kScratchStack) return hipErrorInvalidValue;
 	const TraceGrid tg = trace_grid(n);
 	if (g.depth <= (uint32_t)kLdsStack)
-		hipLaunchKernelGGL((k_trace<true, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr, tg.rays_per_wave);
+		hipLaunchKernelGGL((k_trace<true, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr);
 	else
-		hipLaunchKernelGGL((k_trace<false, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr, tg.rays_per_wave);
+		hipLaunchKernelGGL((k_trace<false, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr);
 	return hipGetLastError();
 }
 
@@ -318,9 +330,9 @@ hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t 
 	if (g.depth > (uint32_t)kScratchStack) return hipErrorInvalidValue;
 	const TraceGrid tg = trace_grid(n);
 	if (g.depth <= (uint32_t)kLdsStack)
-		hipLaunchKernelGGL((k_trace<true, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out, tg.rays_per_wave);
+		hipLaunchKernelGGL((k_trace<true, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out);
 	else
-		hipLaunchKernelGGL((k_trace<false, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out, tg.rays_per_wave);
+		hipLaunchKernelGGL((k_trace<false, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out);
 	return hipGetLastError();
 }
 
