@@ -22,10 +22,10 @@ namespace {
 #define TRACE_LDS_STACK 16
 #endif
 #ifndef TRACE_REFILL_MIN
-#define TRACE_REFILL_MIN 16
+#define TRACE_REFILL_MIN 8
 #endif
 #ifndef TRACE_NODE_MIN_LANES
-#define TRACE_NODE_MIN_LANES 0
+#define TRACE_NODE_MIN_LANES 40
 #endif
 #ifndef TRACE_WAVES_PER_SIMD
 #define TRACE_WAVES_PER_SIMD 4
@@ -111,6 +111,13 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
                                                   rt_hit *__restrict__ hits, double *__restrict__ t64,
                                                   uint8_t *__restrict__ any_out)
 {
+#ifdef TRACE_STATS
+	// diagnostic build only: per-lane trip counts of the three loops (summed into the t64 buffer at the end)
+	unsigned long long st_node_iter = 0, st_node_lanes = 0, st_leaf_iter = 0, st_leaf_lanes = 0, st_outer = 0, st_outer_lanes = 0;
+#define TRACE_COUNT(iter, lanes) do { if (lane == __ffsll((long long)__ballot(true)) - 1) iter++; lanes++; } while (0)
+#else
+#define TRACE_COUNT(iter, lanes) do { } while (0)
+#endif
 	__shared__ uint32_t lds_base[LDS_STACK ? kLdsStack * kBlock : 1];
 	__shared__ uint32_t lds_mask[LDS_STACK ? kLdsStack * kBlock : 1];
 	uint32_t scr_base[LDS_STACK ? 1 : kScratchStack], scr_mask[LDS_STACK ? 1 : kScratchStack];
@@ -163,6 +170,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 		}
 		if (__ballot(active) == 0) break;
 		if (active) {
+			TRACE_COUNT(st_outer, st_outer_lanes);
 			// ---- node phase
 			for (;;) {
 				if ((g_mask & 0xFFu) == 0) {
@@ -173,6 +181,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				}
 				if (l1_hits != 0) break; // two parked leaf groups: wait for the triangle phase
 				// nearest pending child of the group
+				TRACE_COUNT(st_node_iter, st_node_lanes);
 				const uint32_t pos = (uint32_t)__ffs((int)(g_mask & 0xFFu)) - 1u;
 				g_mask &= ~(1u << pos);
 				const uint32_t slot = pos ^ oct;
@@ -228,6 +237,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					else { l1_base = h1.y; l1_m0 = h1.z; l1_m1 = h1.w; l1_hits = leaf_hits; }
 				}
 				if (__ballot(l0_hits == 0) == 0) break; // every lane still descending already holds triangles to test
+				if (TRACE_NODE_MIN_LANES > 0 && __popcll(__ballot(true)) < TRACE_NODE_MIN_LANES) break; // too few lanes left descending
 			}
 			// ---- triangle phase: both parked groups
 			if (l0_hits != 0) {
@@ -239,6 +249,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					const uint32_t meta = ((c < 4 ? l0_m0 : l0_m1) >> (8 * (c & 3))) & 0xFFu;
 					const uint32_t first = l0_base + (meta & 31u), count = meta >> 5;
 					for (uint32_t k = 0; k < count; k++) {
+						TRACE_COUNT(st_leaf_iter, st_leaf_lanes);
 						const uint32_t li = first + k;
 						const double2 a0 = g.tri_a[3 * (size_t)li], a1 = g.tri_a[3 * (size_t)li + 1], a2 = g.tri_a[3 * (size_t)li + 2];
 						// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz)
@@ -285,7 +296,9 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 						h.object = RT_MISS;
 					}
 					reinterpret_cast<uint4 *>(hits)[ray_id] = *reinterpret_cast<uint4 *>(&h);
+#ifndef TRACE_STATS
 					if (t64) t64[ray_id] = best != RT_MISS ? t_best : (double)__int_as_float(0x7f800000);
+#endif
 				}
 				l0_hits = 0;
 				l1_hits = 0;
@@ -293,6 +306,14 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 			}
 		}
 	}
+#ifdef TRACE_STATS
+	if (t64 && n > 1000000) {
+		unsigned long long *sink = reinterpret_cast<unsigned long long *>(t64);
+		atomicAdd(&sink[0], st_node_iter); atomicAdd(&sink[1], st_node_lanes);
+		atomicAdd(&sink[2], st_leaf_iter); atomicAdd(&sink[3], st_leaf_lanes);
+		atomicAdd(&sink[4], st_outer); atomicAdd(&sink[5], st_outer_lanes);
+	}
+#endif
 }
 
 // grid: enough waves to fill the chip, each with a contiguous share of the rays
