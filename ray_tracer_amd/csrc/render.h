@@ -37,6 +37,9 @@ struct Profiler {
 		if (!enabled) return;
 		(void)hipEventRecord(recs.back().stop, s);
 	}
+	// a launch whose item count lives on the device is recorded with a bound and corrected once the count is read back
+	long last() const { return enabled ? (long)recs.size() - 1 : -1; }
+	void set_items(long idx, uint64_t items) { if (idx >= 0 && (size_t)idx < recs.size()) recs[idx].items = items; }
 	void clear()
 	{
 		for (auto &r : recs) { pool.push_back(r.start); pool.push_back(r.stop); }

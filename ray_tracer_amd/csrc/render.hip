@@ -75,6 +75,7 @@ struct Counters {
 	unsigned long long tails;
 	unsigned long long pad;
 };
+constexpr int kMaxBounces = 62; // counter slots per batch; a longer path wraps around (see run_batch)
 constexpr int kShadeBlock = 1024;
 
 struct Impl {
@@ -97,8 +98,9 @@ struct Impl {
 	ConnRec *conn = nullptr;
 	rt_hit *conn_hits = nullptr;
 	uint8_t *conn_any = nullptr;
-	Counters *counters = nullptr;
-	Counters *h_counters = nullptr; // pinned
+	Counters *counters = nullptr;   // kMaxBounces + 2 slots: slot b = paths entering bounce b (low) | connections made at bounce b-1 (high)
+	Counters *h_counters = nullptr; // pinned mirror, filled by asynchronous copies
+	hipEvent_t ev[kMaxBounces + 2] = {};
 	std::vector<float> film_host;
 };
 
@@ -392,14 +394,14 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBan
 // the reference's order; appends connection rays and the continuation ray.
 // ---------------------------------------------------------------------------------------------
 template <int ALG>
-__global__ void __launch_bounds__(kShadeBlock) k_shade(DeviceShade sh, uint32_t n, const rt_ray *__restrict__ rays,
+__global__ void __launch_bounds__(kShadeBlock) k_shade(DeviceShade sh, const uint32_t *__restrict__ n_dev, const rt_ray *__restrict__ rays,
                                                   const PathState *__restrict__ state, const rt_hit *__restrict__ hits,
                                                   rt_ray *__restrict__ next_rays, PathState *__restrict__ next_state,
                                                   rt_ray *__restrict__ conn_rays, ConnRec *__restrict__ conn,
                                                   Counters *__restrict__ counters, float *__restrict__ film)
 {
 	const uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
-	const bool live = idx < n;
+	const bool live = idx < *n_dev;
 	bool survive = false, want_c0 = false, want_c1 = false;
 	rt_ray nr{}, cr0{}, cr1{};
 	ConnRec c0{}, c1{};
@@ -554,12 +556,12 @@ __device__ bool face_hit_exact(const DeviceGeom &g, const DeviceShade &sh, uint3
 // connect: turns visibility results into film contributions
 // ---------------------------------------------------------------------------------------------
 template <int ALG>
-__global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh, uint32_t n, const rt_ray *__restrict__ conn_rays,
+__global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh, const uint32_t *__restrict__ n_dev, const rt_ray *__restrict__ conn_rays,
                                                     const ConnRec *__restrict__ conn, const rt_hit *__restrict__ conn_hits,
                                                     const uint8_t *__restrict__ conn_any, float *__restrict__ film)
 {
 	const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
-	if (idx >= n) return;
+	if (idx >= *n_dev) return;
 	const ConnRec c = conn[idx];
 	const DevBand bd = sh.bands[c.band_kind & 0xFFFFu];
 	const uint32_t kind = c.band_kind >> 16;
@@ -806,8 +808,9 @@ hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, i
 	}
 	HIP_TRY(hipMemsetAsync(rs.d_film, 0, film_elems * sizeof(float), stream)); // renderer.cpp:58
 	if (!im.counters) {
-		HIP_TRY(hipMalloc((void **)&im.counters, sizeof(Counters)));
-		HIP_TRY(hipHostMalloc((void **)&im.h_counters, sizeof(Counters), hipHostMallocDefault));
+		HIP_TRY(hipMalloc((void **)&im.counters, sizeof(Counters) * (kMaxBounces + 2)));
+		HIP_TRY(hipHostMalloc((void **)&im.h_counters, sizeof(Counters) * (kMaxBounces + 2), hipHostMallocDefault));
+		for (auto &e : im.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	}
 	rs.nx = nx; rs.ny = ny; rs.ns = ns; rs.spectral_samples = spectral_samples; rs.algorithm = algorithm; rs.seed = seed;
 	rs.closest_rays = rs.any_rays = rs.camera_samples = 0;
@@ -854,44 +857,89 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 	prof.end(stream);
 	HIP_TRY(hipGetLastError());
 	rs.camera_samples += n_paths;
-	uint32_t n_active = (uint32_t)n_paths;
-	int cur = 0;
-	while (n_active > 0) {
-		HIP_TRY(capture(im.rays[cur], n_active));
-		prof.begin(Profiler::CLOSEST, n_active, stream);
-		HIP_TRY(launch_trace_closest(geom, im.rays[cur], n_active, im.hits, nullptr, stream));
-		prof.end(stream);
-		rs.closest_rays += n_active;
-		HIP_TRY(hipMemsetAsync(im.counters, 0, 16, stream));
-		prof.begin(Profiler::SHADE, n_active, stream);
-		hipLaunchKernelGGL((k_shade<ALG>), dim3((n_active + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, stream, sh, n_active, im.rays[cur],
-		                   im.state[cur], im.hits, im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, im.conn, im.counters, rs.d_film);
-		prof.end(stream);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(im.h_counters, im.counters, 16, hipMemcpyDeviceToHost, stream));
-		HIP_TRY(hipStreamSynchronize(stream));
-		const uint32_t n_next = (uint32_t)im.h_counters->tails, n_conn = (uint32_t)(im.h_counters->tails >> 32);
-		if (ALG != RT_ALG_NAIVE && n_conn > 0) {
-			HIP_TRY(capture(im.conn_rays, n_conn));
-			if (ALG == RT_ALG_NEE) {
-				prof.begin(Profiler::ANY, n_conn, stream);
-				HIP_TRY(launch_trace_any(geom, im.conn_rays, n_conn, im.conn_any, stream));
-				prof.end(stream);
-				rs.any_rays += n_conn;
-			} else {
-				prof.begin(Profiler::CLOSEST, n_conn, stream);
-				HIP_TRY(launch_trace_closest(geom, im.conn_rays, n_conn, im.conn_hits, nullptr, stream));
-				prof.end(stream);
-				rs.closest_rays += n_conn;
+	// Queue sizes stay on the device: every kernel of bounce b reads its item count from the slot the previous
+	// kernel wrote, and the host only sizes grids from upper bounds (paths can only die; at most two connection
+	// rays per path).  Counts are copied back asynchronously; the host runs at most two bounces ahead of the
+	// copies and stops as soon as one of them reports an empty path queue.
+	uint64_t entering = n_paths; // paths entering the first bounce of this round of slots
+	for (;;) {
+		HIP_TRY(hipMemsetAsync(im.counters, 0, sizeof(Counters) * (kMaxBounces + 2), stream));
+		HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)im.counters, (int)entering, 1, stream));
+		im.h_counters[0].tails = entering;
+		uint64_t bound = entering;
+		int known = 0, b = 0, cur = 0;
+		long rec_path[kMaxBounces + 1], rec_conn[kMaxBounces + 1];
+		bool empty = false;
+		for (; b < kMaxBounces; b++) {
+			while (known < b) { // take the counts that have arrived; never run more than two bounces ahead
+				if (b - known > 2 || rs.capture_buf) HIP_TRY(hipEventSynchronize(im.ev[known + 1]));
+				else if (hipEventQuery(im.ev[known + 1]) != hipSuccess) break;
+				known++;
+				bound = std::min<uint64_t>(bound, (uint32_t)im.h_counters[known].tails);
 			}
-			prof.begin(Profiler::CONNECT, n_conn, stream);
-			hipLaunchKernelGGL((k_connect<ALG>), dim3((n_conn + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, geom, sh, n_conn,
-			                   im.conn_rays, im.conn, im.conn_hits, im.conn_any, rs.d_film);
+			if (bound == 0) { empty = true; break; }
+			const uint32_t *n_path = reinterpret_cast<const uint32_t *>(&im.counters[b]);
+			const uint32_t *n_conn = reinterpret_cast<const uint32_t *>(&im.counters[b + 1]) + 1;
+			if (rs.capture_buf) HIP_TRY(capture(im.rays[cur], bound)); // capture mode is synchronous: bound is exact here
+			prof.begin(Profiler::CLOSEST, bound, stream);
+			HIP_TRY(launch_trace_closest(geom, im.rays[cur], bound, im.hits, nullptr, stream, n_path));
+			prof.end(stream);
+			rec_path[b] = prof.last();
+			prof.begin(Profiler::SHADE, bound, stream);
+			hipLaunchKernelGGL((k_shade<ALG>), dim3((unsigned)((bound + kShadeBlock - 1) / kShadeBlock)), dim3(kShadeBlock), 0, stream, sh, n_path,
+			                   im.rays[cur], im.state[cur], im.hits, im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, im.conn,
+			                   &im.counters[b + 1], rs.d_film);
 			prof.end(stream);
 			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipMemcpyAsync(&im.h_counters[b + 1], &im.counters[b + 1], sizeof(Counters), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipEventRecord(im.ev[b + 1], stream));
+			rec_conn[b] = -1;
+			if (ALG != RT_ALG_NAIVE) {
+				uint64_t conn_bound = 2 * bound;
+				if (rs.capture_buf) {
+					HIP_TRY(hipEventSynchronize(im.ev[b + 1]));
+					conn_bound = (uint32_t)(im.h_counters[b + 1].tails >> 32);
+					HIP_TRY(capture(im.conn_rays, conn_bound));
+				}
+				if (conn_bound > 0) {
+					if (ALG == RT_ALG_NEE) {
+						prof.begin(Profiler::ANY, conn_bound, stream);
+						HIP_TRY(launch_trace_any(geom, im.conn_rays, conn_bound, im.conn_any, stream, n_conn));
+						prof.end(stream);
+					} else {
+						prof.begin(Profiler::CLOSEST, conn_bound, stream);
+						HIP_TRY(launch_trace_closest(geom, im.conn_rays, conn_bound, im.conn_hits, nullptr, stream, n_conn));
+						prof.end(stream);
+					}
+					rec_conn[b] = prof.last();
+					prof.begin(Profiler::CONNECT, conn_bound, stream);
+					hipLaunchKernelGGL((k_connect<ALG>), dim3((unsigned)((conn_bound + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, geom, sh,
+					                   n_conn, im.conn_rays, im.conn, im.conn_hits, im.conn_any, rs.d_film);
+					prof.end(stream);
+					HIP_TRY(hipGetLastError());
+					if (rec_conn[b] >= 0) rec_conn[b] = prof.last() - 1;
+				}
+			}
+			cur ^= 1;
 		}
-		n_active = n_next;
-		cur ^= 1;
+		// all counts of this round are on the host after the stream drains: exact statistics and profile items
+		HIP_TRY(hipStreamSynchronize(stream));
+		for (int k = 0; k < b; k++) {
+			const uint64_t np = (uint32_t)im.h_counters[k].tails, nc = (uint32_t)(im.h_counters[k + 1].tails >> 32);
+			rs.closest_rays += np;
+			if (ALG == RT_ALG_NEE) rs.any_rays += nc;
+			else if (ALG == RT_ALG_MIS) rs.closest_rays += nc;
+			prof.set_items(rec_path[k], np);
+			prof.set_items(rec_path[k] >= 0 ? rec_path[k] + 1 : -1, np);
+			if (rec_conn[k] >= 0) { prof.set_items(rec_conn[k], nc); prof.set_items(rec_conn[k] + 1, nc); }
+		}
+		if (empty) break;
+		entering = (uint32_t)im.h_counters[b].tails; // slots exhausted (a path longer than kMaxBounces): go round again
+		if (entering == 0) break;
+		if (cur != 0) { // the next round reads rays[0]/state[0]: the survivors sit in rays[cur]
+			HIP_TRY(hipMemcpyAsync(im.rays[0], im.rays[cur], entering * sizeof(rt_ray), hipMemcpyDeviceToDevice, stream));
+			HIP_TRY(hipMemcpyAsync(im.state[0], im.state[cur], entering * sizeof(PathState), hipMemcpyDeviceToDevice, stream));
+		}
 	}
 	return hipSuccess;
 }
@@ -900,8 +948,8 @@ hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample
 {
 	Impl &im = *impl_of(rs);
 	const uint64_t npix = (uint64_t)rs.nx * rs.ny;
-	// samples per batch: enough paths to fill the chip, bounded queue memory (<= 2^23 paths)
-	uint64_t per_batch = std::max<uint64_t>(1, (1ull << 23) / std::max<uint64_t>(npix, 1));
+	// samples per batch: large batches amortise the nearly empty late bounces; queue memory is about 380 bytes per path (<= 2^25 paths, 12.7 GB)
+	uint64_t per_batch = std::max<uint64_t>(1, (1ull << 25) / std::max<uint64_t>(npix, 1));
 	if (npix * per_batch >= (1ull << 31)) per_batch = 1;
 	if (npix >= (1ull << 31)) { err = "image too large for 32-bit path indices"; return hipErrorInvalidValue; }
 	HIP_TRY(ensure_queues(im, npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1)), err));
@@ -960,7 +1008,10 @@ void render_free(RenderState &rs)
 		if (im.materials) (void)hipFree(im.materials);
 		if (im.light_faces) (void)hipFree(im.light_faces);
 		if (im.bands) (void)hipFree(im.bands);
-		if (im.counters) (void)hipFree(im.counters);
+		if (im.counters) {
+			(void)hipFree(im.counters);
+			for (auto &e : im.ev) if (e) (void)hipEventDestroy(e);
+		}
 		if (im.h_counters) (void)hipHostFree(im.h_counters);
 		delete &im;
 		rs.impl = nullptr;

@@ -4,8 +4,11 @@
 #include "mi355rt.h"
 
 namespace mi355rt {
-// closest hit over n device-resident rays; d_t64 may be null
-hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, hipStream_t stream);
+// closest hit over n device-resident rays; d_t64 may be null.  When d_n is not null the kernel reads the ray count
+// from it (a count produced by an earlier kernel on the same stream) and n is only an upper bound that sizes the grid.
+hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, hipStream_t stream,
+                                const uint32_t *d_n = nullptr);
 // any hit: d_out[i] = 1 when some triangle is hit inside [tmin, tmax]
-hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, uint8_t *d_out, hipStream_t stream);
+hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, uint8_t *d_out, hipStream_t stream,
+                            const uint32_t *d_n = nullptr);
 } // namespace mi355rt

@@ -107,10 +107,11 @@ __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return (floa
 // descending; the fp64 triangle phase runs when a lane holds two parked groups or has run out of nodes,
 // so that it runs with most lanes holding work.
 template <bool LDS_STACK, bool ANY>
-__global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGeom g, const rt_ray *__restrict__ rays, uint64_t n,
+__global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGeom g, const rt_ray *__restrict__ rays, uint64_t n_bound,
                                                   rt_hit *__restrict__ hits, double *__restrict__ t64,
-                                                  uint8_t *__restrict__ any_out)
+                                                  uint8_t *__restrict__ any_out, const uint32_t *__restrict__ n_dev)
 {
+	const uint64_t n = n_dev ? (uint64_t)*n_dev : n_bound;
 #ifdef TRACE_STATS
 	// diagnostic build only: per-lane trip counts of the three loops (summed into the t64 buffer at the end)
 	unsigned long long st_node_iter = 0, st_node_lanes = 0, st_leaf_iter = 0, st_leaf_lanes = 0, st_outer = 0, st_outer_lanes = 0;
@@ -333,27 +334,27 @@ inline TraceGrid trace_grid(uint64_t n)
 
 } // namespace
 
-hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, hipStream_t stream)
+hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, hipStream_t stream, const uint32_t *d_n)
 {
 	if (n == 0) return hipSuccess;
 	if (g.depth > (uint32_t)kScratchStack) return hipErrorInvalidValue;
 	const TraceGrid tg = trace_grid(n);
 	if (g.depth <= (uint32_t)kLdsStack)
-		hipLaunchKernelGGL((k_trace<true, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr);
+		hipLaunchKernelGGL((k_trace<true, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr, d_n);
 	else
-		hipLaunchKernelGGL((k_trace<false, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr);
+		hipLaunchKernelGGL((k_trace<false, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr, d_n);
 	return hipGetLastError();
 }
 
-hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, uint8_t *d_out, hipStream_t stream)
+hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, uint8_t *d_out, hipStream_t stream, const uint32_t *d_n)
 {
 	if (n == 0) return hipSuccess;
 	if (g.depth > (uint32_t)kScratchStack) return hipErrorInvalidValue;
 	const TraceGrid tg = trace_grid(n);
 	if (g.depth <= (uint32_t)kLdsStack)
-		hipLaunchKernelGGL((k_trace<true, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out);
+		hipLaunchKernelGGL((k_trace<true, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out, d_n);
 	else
-		hipLaunchKernelGGL((k_trace<false, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out);
+		hipLaunchKernelGGL((k_trace<false, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out, d_n);
 	return hipGetLastError();
 }
 
