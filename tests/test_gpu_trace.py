@@ -158,3 +158,82 @@ def test_errors(ctx):
     assert e.value.code == capi.ERR_MESH
     with pytest.raises(capi.BackendError):
         ctx.trace_closest(np.zeros((1, 8), dtype=np.float32))  # no mesh after the failed upload
+
+
+def _axis_rays(n, seed, scale=1.0, offset=0.0):
+    """rays built to stress the conservative box tests: zero direction components (positive and negative zero),
+    origins on round coordinates, tiny and huge direction magnitudes"""
+    rng = np.random.default_rng(seed)
+    rays = synth.incoherent_rays(n, seed=seed)
+    k = np.arange(n)
+    rays[k % 5 == 0, 4] = 0.0
+    rays[k % 7 == 0, 5] = -0.0
+    rays[k % 11 == 0, 6] = 0.0
+    rays[k % 13 == 0, 0:3] = np.round(rays[k % 13 == 0, 0:3] * 8) / 8
+    rays[k % 17 == 0, 4:7] *= 1e-3
+    rays[k % 19 == 0, 4:7] *= 1e3
+    bad = np.abs(rays[:, 4:7]).sum(1) == 0
+    rays[bad, 4] = 1.0
+    rays[:, 0:3] = rays[:, 0:3] * scale + offset
+    rays[:, 3] = 1e-3
+    return rays
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1000.0, 5000.0), (1e-3, 0.25)])
+def test_conservative_boxes_against_brute_force(ctx, scale, offset):
+    """the quantised, outward-rounded boxes may only over-accept: every hit the reference's linear scan
+    (HittableList::Hit, no boxes at all) finds must be found, for awkward rays and coordinate ranges"""
+    mesh = synth.soup(4000, 0.08, seed=99)
+    mesh["v"] = mesh["v"] * scale + offset
+    sc = oracle.Scene(mesh)
+    ctx.upload_mesh(mesh)
+    rays = _axis_rays(30000, 5, scale, offset)
+    hits, t64 = ctx.trace_closest(rays, want_t64=True)
+    o_poly, o_tri, o_t = sc.trace_closest(rays, oracle.MODE_LIST_LOWEST)
+    check_closest(hits, t64, o_poly, o_tri, o_t, allow_ties=False)
+    assert 0.3 < (o_poly >= 0).mean()
+    short = rays.copy()
+    short[:, 7] = 0.3 * scale
+    assert np.array_equal(ctx.trace_any(short), sc.trace_any(short, oracle.MODE_LIST))
+
+
+def test_axis_aligned_geometry_and_rays(ctx, cornell_dir):
+    """Cornell walls are axis-aligned (zero-thickness boxes); rays along the axes graze them"""
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 64, 64)
+    sc = oracle.Scene(mesh)
+    ctx.upload_mesh(mesh)
+    rays = _axis_rays(40000, 8, 0.95)
+    hits, t64 = ctx.trace_closest(rays, want_t64=True)
+    o_poly, o_tri, o_t = sc.trace_closest(rays, oracle.MODE_LIST_LOWEST)
+    check_closest(hits, t64, o_poly, o_tri, o_t)
+
+
+def test_deep_tree_uses_the_scratch_stack(ctx):
+    """a long thin chain of triangles gives a tree deeper than the LDS stack holds; the scratch variant must agree"""
+    n = 3000
+    x = np.cumsum(np.geomspace(1e-6, 1.0, n))  # sizes growing geometrically: SAH splits one triangle off at a time
+    v = np.zeros((n, 3, 3))
+    v[:, 0] = np.stack([x, np.zeros(n), np.zeros(n)], 1)
+    v[:, 1] = np.stack([x + np.geomspace(1e-6, 1.0, n) * 0.9, np.zeros(n), np.zeros(n)], 1)
+    v[:, 2] = np.stack([x, np.geomspace(1e-6, 1.0, n), np.zeros(n)], 1)
+    idx = np.arange(3 * n, dtype=np.int64)
+    mesh = {"v": v.reshape(-1, 3), "vt": np.zeros((0, 3)), "vn": np.tile([[0, 0, 1.0]], (n, 1)),
+            "corners": np.stack([idx, np.full(3 * n, -1), idx // 3], 1), "face_begin": np.arange(0, 3 * n + 1, 3, dtype=np.uint64),
+            "object_begin": np.array([0, n], dtype=np.uint64), "names": ["chain"]}
+    sc = oracle.Scene(mesh)
+    ctx.upload_mesh(mesh)
+    assert ctx.stats()["bvh_depth"] > 16  # more levels than the LDS stack holds
+    rng = np.random.default_rng(3)
+    m = 20000
+    rays = np.zeros((m, 8), dtype=np.float32)
+    t = rng.integers(0, n, m)
+    p = v[t, 0] + 0.3 * (v[t, 1] - v[t, 0]) + 0.3 * (v[t, 2] - v[t, 0])
+    h = np.geomspace(1e-6, 1.0, n)[t][:, None]
+    rays[:, 0:3] = p + np.array([0, 0, 1.0]) * h
+    rays[:, 3] = 1e-3
+    rays[:, 4:7] = (np.array([0, 0, -1.0]) + rng.normal(size=(m, 3)) * 0.01) * h
+    rays[:, 7] = np.inf
+    hits, t64 = ctx.trace_closest(rays, want_t64=True)
+    o_poly, o_tri, o_t = sc.trace_closest(rays, oracle.MODE_LIST_LOWEST)
+    check_closest(hits, t64, o_poly, o_tri, o_t)
+    assert (o_poly >= 0).mean() > 0.5
