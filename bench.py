@@ -33,6 +33,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # bytes/s
 
 
+def recorded_traffic(pattern, kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC summary matching `pattern`
+    (tools/profile.sh + tools/traffic_from_profile.py on this same command); None when there is none"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None, None
+    rec = json.load(open(files[-1]))
+    k = rec["kernels"].get(kernel)
+    return (k, os.path.relpath(files[-1], ROOT)) if k else (None, None)
+
+
 def b_ray(nodes_per_ray, tris_per_ray):
     """algorithmic bytes per closest-hit ray: ray in (32) + hit out (16) + 64 B per interior-node visit
     + 48 B per triangle test of an ordered, t-pruned BVH2 walk"""
@@ -132,6 +144,16 @@ def soup_leg(args, ctx, capi, synth, oracle, torch, rank, log):
         res["achieved_gbs"] = res["mrays_per_s"] * 1e6 * res["b_ray"] / 1e9
         res["frac_hbm"] = res["achieved_gbs"] * 1e9 / HBM_PEAK
         res["parity_prim_mismatch"] = int((h[:, 1] != poly).sum())
+    tr, tr_file = recorded_traffic("r*_soup1m_traffic.json", "k_trace<true, false>")
+    if tr is not None and n == 1000000 and m == 1 << 24:
+        # what bounds this kernel: the rate at which the memory side of the L2 serves random 128-byte lines
+        # (tools/calib/random_lines.hip: 53 G lines/s from HBM, 57 G lines/s from the Infinity Cache)
+        res["traffic_bytes_per_launch"] = tr["bytes_per_launch"]
+        res["traffic_source"] = tr_file
+        res["lines_per_ray"] = tr["read_requests_per_launch"] / m
+        res["line_rate_g_per_s"] = tr["read_requests_per_launch"] / (res["kernel_ms_per_launch"] * 1e-3) / 1e9
+        res["frac_of_random_line_rate"] = res["line_rate_g_per_s"] / 57.0
+        res["traffic_frac_hbm"] = tr["bytes_per_launch"] / (res["kernel_ms_per_launch"] * 1e-3) / HBM_PEAK
     return res
 
 
@@ -219,11 +241,18 @@ def main():
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "k_trace (closest hit)", "kernel_ms_avg": k["ms"] / max(k["launches"], 1), "launches": k["launches"],
                 "rays": k["items"], "kernel_ms_total": k["ms"], "mrays_per_s_in_kernel": k["items"] / max(k["ms"], 1e-9) / 1e3}
+        tr, tr_file = recorded_traffic("r*_bench_traffic.json", "k_trace<true, false>")
+        if tr is not None:
+            roof["traffic"] = tr["bytes_per_launch"]
+            roof["traffic_note"] = ("bytes per launch on the memory side of the L2 (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes "
+                                    "over this command, recorded in %s); far below the algorithmic bytes because the small tree stays "
+                                    "in cache: only rays and hits reach HBM" % tr_file)
         if cpu is not None:
             bytes_per_ray = b_ray(cpu["cornell_nodes_per_ray"], cpu["cornell_tris_per_ray"])
             roof["achieved"] = k["items"] * bytes_per_ray / (k["ms"] * 1e-3) / 1e9
             roof["frac"] = roof["achieved"] * 1e9 / HBM_PEAK
             roof["bytes_per_ray"] = bytes_per_ray
+            roof["algorithmic_bytes_per_launch"] = k["items"] / max(k["launches"], 1) * bytes_per_ray
             roof["nodes_per_ray"], roof["tris_per_ray"] = cpu["cornell_nodes_per_ray"], cpu["cornell_tris_per_ray"]
         line = {
             "metric": "spp/s at 1080p (Cornell box, NEE+MIS wavefront integrator); the incoherent closest-hit Mrays/s half of the metric is under aux",

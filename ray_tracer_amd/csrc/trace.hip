@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 	const uint64_t n = n_dev ? (uint64_t)*n_dev : n_bound;
 #ifdef TRACE_STATS
 	// diagnostic build only: per-lane trip counts of the three loops (summed into the t64 buffer at the end)
-	unsigned long long st_node_iter = 0, st_node_lanes = 0, st_leaf_iter = 0, st_leaf_lanes = 0, st_outer = 0, st_outer_lanes = 0;
+	unsigned long long st_node_iter = 0, st_node_lanes = 0, st_leaf_iter = 0, st_leaf_lanes = 0, st_outer = 0, st_outer_lanes = 0, st_in_iter = 0, st_in_lanes = 0;
 #define TRACE_COUNT(iter, lanes) do { if (lane == __ffsll((long long)__ballot(true)) - 1) iter++; lanes++; } while (0)
 #else
 #define TRACE_COUNT(iter, lanes) do { } while (0)
@@ -124,8 +124,17 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 	uint32_t scr_base[LDS_STACK ? 1 : kScratchStack], scr_mask[LDS_STACK ? 1 : kScratchStack];
 	const int lane = threadIdx.x & 63;
 	const unsigned long long lt = (1ull << lane) - 1ull;
-	const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / 64);
+	// Workgroups go to the eight XCDs round robin (workgroup b runs on XCD b mod 8), and every XCD has an L2 of
+	// its own.  Each XCD therefore takes one contiguous eighth of the 64-ray chunks, and its waves walk through
+	// that eighth together (wave w of the XCD owns chunks w, w + W, ...): when the caller has ordered the rays
+	// spatially, the waves that share an L2 work in the same part of the tree at the same time.
+	const bool by_xcd = (gridDim.x & 7u) == 0;
+	const uint64_t n_chunks = (n + 63) >> 6;
+	const uint64_t n_waves = by_xcd ? (uint64_t)(gridDim.x >> 3) * (kBlock / 64) : (uint64_t)gridDim.x * (kBlock / 64);
+	const uint64_t wave_id = by_xcd ? (uint64_t)(blockIdx.x >> 3) * (kBlock / 64) + (threadIdx.x >> 6)
+	                                : (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	const uint64_t chunk_lo = by_xcd ? n_chunks * (blockIdx.x & 7u) / 8 : 0;
+	const uint64_t chunk_hi = by_xcd ? n_chunks * ((blockIdx.x & 7u) + 1) / 8 : n_chunks;
 	uint64_t next = 0; // position in this wave's own sequence of rays
 
 	bool active = false;
@@ -142,12 +151,13 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 	for (;;) {
 		// ---- hand new rays to idle lanes
 		const unsigned long long idle = __ballot(!active);
-		if (idle != 0 && ((next >> 6) * n_waves + wave_id) * 64 < n) {
+		if (idle != 0 && chunk_lo + (next >> 6) * n_waves + wave_id < chunk_hi) {
 			const int nidle = __popcll(idle);
 			if (nidle >= kRefillMin) {
 				const uint64_t seq = next + (uint64_t)__popcll(idle & lt);
-				const uint64_t mine = ((seq >> 6) * n_waves + wave_id) * 64 + (seq & 63);
-				if (!active && mine < n) {
+				const uint64_t chunk = chunk_lo + (seq >> 6) * n_waves + wave_id;
+				const uint64_t mine = chunk * 64 + (seq & 63);
+				if (!active && chunk < chunk_hi && mine < n) {
 					const float4 ra = reinterpret_cast<const float4 *>(rays)[2 * mine];
 					const float4 rb = reinterpret_cast<const float4 *>(rays)[2 * mine + 1];
 					ray_id = mine;
@@ -256,6 +266,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 						// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz)
 						const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
 						if (!(t >= r.tmin && t <= t_best)) continue;
+						TRACE_COUNT(st_in_iter, st_in_lanes);
 						const double2 b0 = g.tri_b[3 * (size_t)li], b1 = g.tri_b[3 * (size_t)li + 1], b2 = g.tri_b[3 * (size_t)li + 2];
 						// b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
 						if (!inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) continue;
@@ -313,6 +324,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 		atomicAdd(&sink[0], st_node_iter); atomicAdd(&sink[1], st_node_lanes);
 		atomicAdd(&sink[2], st_leaf_iter); atomicAdd(&sink[3], st_leaf_lanes);
 		atomicAdd(&sink[4], st_outer); atomicAdd(&sink[5], st_outer_lanes);
+		atomicAdd(&sink[6], st_in_iter); atomicAdd(&sink[7], st_in_lanes);
 	}
 #endif
 }

@@ -41,6 +41,8 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
 for k in sorted(acc):
+    if k.startswith("at::"):
+        continue  # torch's own helper kernels (film set-up and checks in bench.py)
     print(k)
     for c in sorted(acc[k]):
         # rocprofv3 emits one row per dispatch (and per dimension instance for some counters)
