@@ -81,6 +81,8 @@ __device__ __forceinline__ float next_up(float x) // smallest float > x for fini
 }
 
 constexpr int kRefillMin = TRACE_REFILL_MIN; // idle lanes in a wave before it takes new rays
+constexpr float kBigInv = 1.2089258196146292e24f;   // 2^80: stands in for 1/d on an axis the ray does not move along
+constexpr float kTinyDir = 8.673617379884035e-19f;  // 2^-60, relative to the largest component
 
 // bit p of the result = bit (p ^ oct) of x, for 8-bit x: children sit in slots whose bits say on which side of
 // the node centre they lie; after this permutation the lowest set bit is the child nearest along the ray
@@ -139,7 +141,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 
 	bool active = false;
 	uint64_t ray_id = 0;
-	float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tmin_f = 0, tfar_f = 0;
+	float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tmin_f = 0, tfar_f = 0, rscale = 1.0f;
 	double t_best = 0.0;
 	uint32_t best = RT_MISS, best_tri = RT_MISS, oct = 0;
 	bool found_any = false;
@@ -163,15 +165,37 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					ray_id = mine;
 					ox = ra.x; oy = ra.y; oz = ra.z; tmin_f = ra.w;
 					dx = rb.x; dy = rb.y; dz = rb.z; tfar_f = rb.w;
-					ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
-					oct = (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
+					// Box tests run on the direction scaled by a power of two so that its largest component lies in
+					// [1, 2): t_box = t * rscale.  The scaling is exact and makes the constants below independent of the
+					// length of the direction (the reference's connection rays are not normalised).
+					// A component that is zero or negligible against the largest one would turn slab distances into NaN or
+					// overflow, and NaN drops out of min/max: every box would pass and the ray would walk the whole tree.
+					// Such an axis gets a large finite inverse and is flagged (bits 3..5 of oct): the node test then widens
+					// the box by one grid cell on that axis, which makes it "origin inside the slab, any t" (the ray moves
+					// less than 2^-60 of its travel along that axis, far less than a cell).
+					int e2;
+					(void)frexpf(fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)), &e2);
+					rscale = ldexpf(1.0f, e2 - 1);
+					const float sdx = ldexpf(dx, 1 - e2), sdy = ldexpf(dy, 1 - e2), sdz = ldexpf(dz, 1 - e2);
+					const bool zx = fabsf(sdx) < kTinyDir, zy = fabsf(sdy) < kTinyDir, zz = fabsf(sdz) < kTinyDir;
+					ix = zx ? kBigInv : 1.0f / sdx; iy = zy ? kBigInv : 1.0f / sdy; iz = zz ? kBigInv : 1.0f / sdz;
+					oct = (!zx && dx < 0.0f ? 1u : 0u) | (!zy && dy < 0.0f ? 2u : 0u) | (!zz && dz < 0.0f ? 4u : 0u) |
+					      (zx ? 8u : 0u) | (zy ? 16u : 0u) | (zz ? 32u : 0u);
+					tfar_f = isinf(rb.w) ? rb.w : next_up(rb.w * rscale); // rounded up: a product that underflows must not shrink the range
 					t_best = isinf(rb.w) ? DBL_MAX : (double)rb.w; // t_max; shrinks to the closest accepted t
 					best = RT_MISS;
 					best_tri = RT_MISS;
 					found_any = false;
 					sp = 0;
 					g_base = 0;                       // the root as a one-child group
-					g_mask = (1u << oct) | (1u << 8); // slot 0 lands on position 0 ^ oct
+					g_mask = (1u << (oct & 7u)) | (1u << 8); // slot 0 lands on position 0 ^ octant
+					// A NaN anywhere in the ray, a zero direction or an infinite direction component makes every plane distance
+					// of the exact test NaN, zero or infinite with a NaN hit point: the reference finds nothing.  The box tests would over-accept such a
+					// ray at every node (NaN drops out of min/max), i.e. walk the whole tree, so it is answered here.
+					const bool sound = ra.x == ra.x && ra.y == ra.y && ra.z == ra.z && ra.w == ra.w && rb.x == rb.x && rb.y == rb.y &&
+					                   rb.z == rb.z && rb.w == rb.w && !(rb.x == 0.0f && rb.y == 0.0f && rb.z == 0.0f) &&
+					                   !isinf(rb.x) && !isinf(rb.y) && !isinf(rb.z);
+					if (!sound) g_mask = 0;
 					l0_hits = 0;
 					l1_hits = 0;
 					active = true;
@@ -195,7 +219,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				TRACE_COUNT(st_node_iter, st_node_lanes);
 				const uint32_t pos = (uint32_t)__ffs((int)(g_mask & 0xFFu)) - 1u;
 				g_mask &= ~(1u << pos);
-				const uint32_t slot = pos ^ oct;
+				const uint32_t slot = pos ^ (oct & 7u);
 				const uint32_t rel = (uint32_t)__popc((g_mask >> 8) & ((1u << slot) - 1u));
 				const uint32_t node = g_base + rel;
 				if ((g_mask & 0xFFu) != 0) { // siblings left: keep the group for later
@@ -215,15 +239,21 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				const float ax = (__uint_as_float(h0.x) - ox) * ix, ay = (__uint_as_float(h0.y) - oy) * iy, az = (__uint_as_float(h0.z) - oz) * iz;
 				const float kx = sx * ix, ky = sy * iy, kz = sz * iz;
 				const float wid = 2.384185791015625e-7f; // 2^-22
-				const float axn = fmaf(-wid, fabsf(ax), ax), axf = fmaf(wid, fabsf(ax), ax);
-				const float ayn = fmaf(-wid, fabsf(ay), ay), ayf = fmaf(wid, fabsf(ay), ay);
-				const float azn = fmaf(-wid, fabsf(az), az), azf = fmaf(wid, fabsf(az), az);
+				float axn = fmaf(-wid, fabsf(ax), ax), axf = fmaf(wid, fabsf(ax), ax);
+				float ayn = fmaf(-wid, fabsf(ay), ay), ayf = fmaf(wid, fabsf(ay), ay);
+				float azn = fmaf(-wid, fabsf(az), az), azf = fmaf(wid, fabsf(az), az);
+				if (oct >> 3) { // rare: a direction component is zero; k* is then +cell * kBigInv
+					if (oct & 8u) { axn -= kx; axf += kx; }
+					if (oct & 16u) { ayn -= ky; ayf += ky; }
+					if (oct & 32u) { azn -= kz; azf += kz; }
+				}
 				// entry plane is the lower bound when the direction component is positive, else the upper bound
 				const bool px = (oct & 1u) == 0, py = (oct & 2u) == 0, pz = (oct & 4u) == 0;
 				const uint32_t nx0 = px ? q0.x : q1.z, nx1 = px ? q0.y : q1.w, fx0 = px ? q1.z : q0.x, fx1 = px ? q1.w : q0.y;
 				const uint32_t ny0 = py ? q0.z : q2.x, ny1 = py ? q0.w : q2.y, fy0 = py ? q2.x : q0.z, fy1 = py ? q2.y : q0.w;
 				const uint32_t nz0 = pz ? q1.x : q2.z, nz1 = pz ? q1.y : q2.w, fz0 = pz ? q2.z : q1.x, fz1 = pz ? q2.w : q1.y;
 				uint32_t hitmask = 0;
+				const float tmin_s = tmin_f * rscale; // exact, or rounded towards zero when it underflows: the safe side
 #pragma unroll
 				for (int j = 0; j < 8; j++) {
 					const int k = j & 3;
@@ -233,7 +263,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					const float tfx = fmaf(byte_to_float(j < 4 ? fx0 : fx1, k), kx, axf);
 					const float tfy = fmaf(byte_to_float(j < 4 ? fy0 : fy1, k), ky, ayf);
 					const float tfz = fmaf(byte_to_float(j < 4 ? fz0 : fz1, k), kz, azf);
-					const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin_f));
+					const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin_s));
 					const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tfar_f));
 					// relative slack for the fma roundings; an empty slot has qlo 255 > qhi 0 on every axis and never passes
 					if (tn <= fmaf(fabsf(tf), 1e-6f, tf)) hitmask |= 1u << j;
@@ -242,7 +272,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				// turn into inf/NaN and drop out of min/max) is harmless: its imask bit is 0 and its meta count is 0
 				const uint32_t leaf_hits = hitmask & ~imask;
 				g_base = h1.x;
-				g_mask = permute_by_octant(hitmask & imask, oct) | (imask << 8);
+				g_mask = permute_by_octant(hitmask & imask, oct & 7u) | (imask << 8);
 				if (leaf_hits != 0) {
 					if (l0_hits == 0) { l0_base = h1.y; l0_m0 = h1.z; l0_m1 = h1.w; l0_hits = leaf_hits; }
 					else { l1_base = h1.y; l1_m0 = h1.z; l1_m1 = h1.w; l1_hits = leaf_hits; }
@@ -276,8 +306,9 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 							t_best = t;
 							best = li;
 							best_tri = tri;
-							float tf = (float)t;
-							if ((double)tf < t) tf = next_up(tf);
+							const double ts = t * (double)rscale;
+							float tf = (float)ts;
+							if ((double)tf < ts) tf = next_up(tf);
 							tfar_f = tf;
 						}
 					}

@@ -22,34 +22,53 @@ void Renderer::Load(const char *objfilename) // renderer.cpp:18-22 (the parser's
 {
 	obj_loader.Clear();
 	obj_loader.Load(objfilename);
-	std::vector<double> v, vt, vn;
-	std::vector<int64_t> corners;
-	std::vector<uint64_t> face_begin{0}, object_begin{0};
-	for (auto &p : obj_loader.v) { v.push_back(p[0]); v.push_back(p[1]); v.push_back(p[2]); }
-	for (auto &p : obj_loader.vt) { vt.push_back(p[0]); vt.push_back(p[1]); vt.push_back(p[2]); }
-	for (auto &p : obj_loader.vn) { vn.push_back(p[0]); vn.push_back(p[1]); vn.push_back(p[2]); }
+	tables = MeshTables();
+	for (auto &p : obj_loader.v) { tables.v.push_back(p[0]); tables.v.push_back(p[1]); tables.v.push_back(p[2]); }
+	for (auto &p : obj_loader.vt) { tables.vt.push_back(p[0]); tables.vt.push_back(p[1]); tables.vt.push_back(p[2]); }
+	for (auto &p : obj_loader.vn) { tables.vn.push_back(p[0]); tables.vn.push_back(p[1]); tables.vn.push_back(p[2]); }
 	for (auto *o : obj_loader.objects) {
 		for (auto &face : o->faces) {
-			for (auto &c : face) { corners.push_back(c[0]); corners.push_back(c[1]); corners.push_back(c[2]); }
-			face_begin.push_back(corners.size() / 3);
+			for (auto &c : face) { tables.corners.push_back(c[0]); tables.corners.push_back(c[1]); tables.corners.push_back(c[2]); }
+			tables.face_begin.push_back(tables.corners.size() / 3);
 		}
-		object_begin.push_back(face_begin.size() - 1);
+		tables.object_begin.push_back(tables.face_begin.size() - 1);
+		tables.object_names.push_back(o->name);
 	}
-	rt_mesh m{v.data(), v.size() / 3, vt.data(), vt.size() / 3, vn.data(), vn.size() / 3, corners.data(),
-	          face_begin.data(), face_begin.size() - 1, object_begin.data(), (uint32_t)(object_begin.size() - 1)};
+	Upload();
+}
+
+bool Renderer::LoadPly(const char *plyfilename, const char *object_name, PlyNormals normals)
+{
+	if (!ply_loader.Load(plyfilename)) {
+		last_error = ply_loader.error;
+		std::fprintf(stderr, "%s\n", last_error.c_str());
+		return false;
+	}
+	size_t dropped = AppendPly(ply_loader, object_name, normals, tables);
+	if (dropped) std::fprintf(stderr, "%zu faces of %s dropped (fewer than 3 corners or index out of range)\n", dropped, plyfilename);
+	return Upload();
+}
+
+bool Renderer::Upload(void)
+{
+	rt_mesh m{tables.v.data(), tables.v.size() / 3, tables.vt.data(), tables.vt.size() / 3, tables.vn.data(), tables.vn.size() / 3,
+	          tables.corners.data(), tables.face_begin.data(), tables.face_begin.size() - 1, tables.object_begin.data(),
+	          (uint32_t)(tables.object_begin.size() - 1)};
 	if (!gpu || rt_upload_mesh(gpu, &m) != RT_OK) {
 		last_error = gpu ? rt_last_error(gpu) : rt_last_error(nullptr);
 		std::fprintf(stderr, "%s\n", last_error.c_str());
+		return false;
 	}
+	return true;
 }
 
 bool Renderer::LoadMaterials(const std::map<std::string, std::shared_ptr<NodeMaterial>> &materials) // renderer.cpp:24-44
 {
 	std::vector<rt_material> recs;
-	for (size_t i = 0; i < obj_loader.objects.size(); i++) {
-		auto itr = materials.find(obj_loader.objects[i]->name);
+	for (size_t i = 0; i < tables.object_names.size(); i++) { // obj objects in file order (as the reference), then PLY objects
+		auto itr = materials.find(tables.object_names[i]);
 		if (itr == materials.end()) {
-			std::fprintf(stderr, "Material is unset for %s\n", obj_loader.objects[i]->name.c_str());
+			std::fprintf(stderr, "Material is unset for %s\n", tables.object_names[i].c_str());
 			return false;
 		}
 		recs.push_back(itr->second->Record());
@@ -63,6 +82,8 @@ bool Renderer::LoadMaterials(const std::map<std::string, std::shared_ptr<NodeMat
 void Renderer::Clear(void) // renderer.cpp:47-51
 {
 	obj_loader.Clear();
+	ply_loader.Clear();
+	tables = MeshTables();
 	img_updated = false;
 }
 

@@ -9,6 +9,7 @@
 #include "materialnode.h"
 #include "mi355rt.h"
 #include "obj.h"
+#include "ply.h"
 
 namespace mi355host {
 
@@ -23,6 +24,9 @@ public:
 	Renderer(void);
 	~Renderer();
 	void Load(const char *objfilename);
+	// addition (the reference parses PLY files but never renders them, object.cpp:153-233): the file becomes one more
+	// object called `object_name`, appended to what Load / earlier LoadPly calls brought in; false on a parse error
+	bool LoadPly(const char *plyfilename, const char *object_name, PlyNormals normals = PlyNormals::Auto);
 	bool LoadMaterials(const std::map<std::string, std::shared_ptr<NodeMaterial>> &materials);
 	void Clear(void);
 	void RenderImage(int nx, int ny, int ns, int spectral_samples, bool enable_openmp, bool print_progress = false);
@@ -30,6 +34,7 @@ public:
 	std::vector<Spectrum> spectrum_img;
 	std::vector<dvec3> preview_img;
 	obj obj_loader;
+	ply ply_loader; // the last PLY file read by LoadPly
 	LensCamera cam;
 	bool preview_img_flag = true;
 	bool img_updated = false;
@@ -42,6 +47,8 @@ public:
 	std::string last_error;
 
 private:
+	bool Upload(void);
+	MeshTables tables;              // what the device holds: obj objects first, then one object per LoadPly call
 	rt_context *gpu = nullptr;
 };
 

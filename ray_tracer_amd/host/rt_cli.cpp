@@ -2,6 +2,9 @@
 // camera set-up the GUI performs (scene.cpp:866-867), with the linear film dumped for tests.
 //   rt_cli --obj scene.obj --materials materials.json --objmatmap map.json [--width W --height H --sample S]
 //          [--algorithm naive|nee|mis] [--seed N] [--spectral 30] [--film out.f64] [--ppm out.ppm] [--records out.f64]
+//          [--ply mesh.ply --ply-object NAME --ply-normals auto|file|flat|smooth]   one more object from a PLY file
+//   rt_cli --ply mesh.ply --dump-ply out.bin       host only: the parsed tables (u64 nv, nf, ni, has_normals; f64 [nv][6];
+//                                                  u64 [nf+1]; i32 [ni]) for tests
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,7 +16,7 @@ using namespace mi355host;
 
 int main(int argc, char **argv)
 {
-	std::string objp, matp, mapp, film_out, ppm_out, rec_out, alg = "mis";
+	std::string objp, matp, mapp, film_out, ppm_out, rec_out, alg = "mis", plyp, ply_object = "ply", ply_normals = "auto", ply_dump;
 	int w = 64, h = 64, ns = 4, spectral = 30;
 	unsigned long long seed = 1;
 	for (int i = 1; i + 1 < argc; i += 2) {
@@ -23,7 +26,21 @@ int main(int argc, char **argv)
 		else if (k == "--sample") ns = std::atoi(v.c_str()); else if (k == "--algorithm") alg = v;
 		else if (k == "--seed") seed = std::strtoull(v.c_str(), nullptr, 10); else if (k == "--spectral") spectral = std::atoi(v.c_str());
 		else if (k == "--film") film_out = v; else if (k == "--ppm") ppm_out = v; else if (k == "--records") rec_out = v;
+		else if (k == "--ply") plyp = v; else if (k == "--ply-object") ply_object = v; else if (k == "--ply-normals") ply_normals = v;
+		else if (k == "--dump-ply") ply_dump = v;
 		else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+	}
+	if (!ply_dump.empty()) {
+		ply p;
+		if (!p.Load(plyp.c_str())) { std::fprintf(stderr, "%s\n", p.error.c_str()); return 7; }
+		std::ofstream f(ply_dump, std::ios::binary);
+		uint64_t head[4] = {p.n_vertices(), p.n_faces(), p.face_index.size(), p.has_normals() ? 1u : 0u};
+		f.write((const char *)head, sizeof(head));
+		f.write((const char *)p.vertex_data.data(), sizeof(double) * p.vertex_data.size());
+		f.write((const char *)p.face_begin.data(), sizeof(uint64_t) * p.face_begin.size());
+		f.write((const char *)p.face_index.data(), sizeof(int32_t) * p.face_index.size());
+		for (auto &e : p.elements) std::printf("element %s %zu %zu\n", e.name.c_str(), e.num_of_elements, e.num_of_property);
+		return 0;
 	}
 	if (objp.empty() || matp.empty() || mapp.empty()) { std::fprintf(stderr, "need --obj --materials --objmatmap\n"); return 2; }
 	try {
@@ -50,6 +67,11 @@ int main(int argc, char **argv)
 		if (!r.last_error.empty()) return 3;
 		r.seed = seed;
 		r.Load(objp.c_str());
+		if (!plyp.empty()) {
+			PlyNormals mode = ply_normals == "file" ? PlyNormals::File : ply_normals == "flat" ? PlyNormals::Flat
+			                : ply_normals == "smooth" ? PlyNormals::Smooth : PlyNormals::Auto;
+			if (!r.LoadPly(plyp.c_str(), ply_object.c_str(), mode)) return 7;
+		}
 		if (!r.LoadMaterials(by_object)) { std::fprintf(stderr, "LoadMaterials failed: %s\n", r.last_error.c_str()); return 4; }
 		r.cam.film_height = 0.024;
 		r.cam.film_width = 0.024 * w / h; // scene.cpp:668

@@ -4,7 +4,7 @@ import numpy as np
 
 from . import capi
 from .camera import LensCamera
-from .scene_io import Obj
+from .scene_io import Obj, Ply
 
 Naive, NEE, MIS, NaiveBDPTType, MISBDPTType = range(5)  # enum RenderingAlgorithm, renderer.h:12-18
 
@@ -33,6 +33,18 @@ class Renderer:
         self.mesh = self.obj_loader.to_mesh()
         self.ctx.upload_mesh(self.mesh)
 
+    def LoadPly(self, plyfilename, object_name, normals="auto"):
+        """Addition (the reference parses PLY files, ply.cpp:13-81, but never renders them, object.cpp:153-233): the
+        file becomes one more object called `object_name`, appended to what Load or earlier LoadPly calls brought in.
+        False on a parse error."""
+        self.ply_loader = Ply()
+        if not self.ply_loader.Load(plyfilename):
+            print(self.ply_loader.error)
+            return False
+        self.mesh = self.ply_loader.to_mesh(object_name, normals, into=getattr(self, "mesh", None))
+        self.ctx.upload_mesh(self.mesh)
+        return True
+
     def LoadMesh(self, mesh):
         """Same as Load for a mesh already in memory (synthetic scenes)."""
         self.obj_loader = Obj()
@@ -44,7 +56,7 @@ class Renderer:
         """materials: {obj object name: NodeMaterial}.  False when an object has no entry or no
         object is a light, as the reference returns."""
         records = []
-        for name in self.obj_loader.object_names():
+        for name in self.mesh["names"]:  # obj objects in file order (as the reference), then PLY objects
             m = materials.get(name)
             if m is None:
                 print("Material is unset for %s" % name)

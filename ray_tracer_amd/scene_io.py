@@ -1,5 +1,7 @@
 """The reference's data formats, host side: OBJ subset (obj.cpp), materials JSON (materialnode.cpp),
 object->material map and project JSON (scene.cpp).  Output is the flat tables the C ABI takes."""
+import ctypes
+import ctypes.util
 import json
 import os
 
@@ -13,17 +15,14 @@ NBINS = 30
 # ----------------------------------------------------------------------------------------------
 # OBJ (obj.cpp:6-152)
 # ----------------------------------------------------------------------------------------------
+_libc = ctypes.CDLL(ctypes.util.find_library("c"))
+_libc.atof.restype = ctypes.c_double
+_libc.atof.argtypes = [ctypes.c_char_p]
+
+
 def _atof(s):
-    # atof: longest valid prefix, 0.0 when there is none
-    try:
-        return float(s)
-    except ValueError:
-        for end in range(len(s), 0, -1):
-            try:
-                return float(s[:end])
-            except ValueError:
-                pass
-        return 0.0
+    # the C library's own atof: longest valid prefix (decimal, hex float, inf, nan), 0.0 when there is none
+    return _libc.atof(s.encode("latin-1") if isinstance(s, str) else s)
 
 
 def _atoi(s):
@@ -125,6 +124,335 @@ class Obj:
             "object_begin": np.asarray(object_begin, dtype=np.uint64),
             "names": self.object_names(),
         }
+
+
+# ----------------------------------------------------------------------------------------------
+# PLY (ply.cpp:13-158) and its bridge to the mesh tables
+# ----------------------------------------------------------------------------------------------
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "<i2", "int16": "<i2", "ushort": "<u2",
+              "uint16": "<u2", "int": "<i4", "int32": "<i4", "uint": "<u4", "uint32": "<u4", "float": "<f4", "float32": "<f4",
+              "double": "<f8", "float64": "<f8"}
+
+
+def _tok(line):
+    return line.split()  # bytes.split(): the whitespace set of `iss >> s` in the C locale
+
+
+class Ply:
+    """Mirror of the reference `ply` container (ply.h:19-35) with flat tables:
+    vertices [n, 6] = position and normal (reference vertices[i][0], vertices[i][1]),
+    faces as face_index[face_begin[i]:face_begin[i+1]].  ASCII files are read with the reference's token
+    rules (a missing token repeats the previous one of its line, atof/atoi prefixes, elements[0] and
+    elements[1] taken as vertices and faces whatever their names); binary little-endian files are an addition."""
+
+    def __init__(self):
+        self.elements = []  # dicts: name, num_of_elements, num_of_property
+        self.vertices = np.zeros((0, 6))
+        self.face_index = np.zeros(0, dtype=np.int32)
+        self.face_begin = np.zeros(1, dtype=np.uint64)
+        self.binary = False
+        self.error = ""
+
+    def has_normals(self):
+        return bool(self.elements) and self.elements[0]["num_of_property"] >= 6
+
+    def Load(self, filename):
+        self.__init__()
+        try:
+            with open(filename, "rb") as f:
+                data = f.read()
+        except OSError:
+            self.error = "cannot open %s" % filename
+            return False
+        if not data:
+            self.error = "empty file %s" % filename
+            return False
+        # ---- header.  The std::ifstream calls of ply.cpp with libstdc++'s state rules, which decide what the reference
+        # reads from truncated files: an input function on a stream that is not good() sets failbit and does nothing
+        # else (a getline that fails this way leaves the caller's line as it was; one that finds the stream good but
+        # at its end erases the line)
+        st = {"pos": 0, "eof": False, "fail": False}
+        n = len(data)
+
+        def getline(line):
+            if st["eof"] or st["fail"]:
+                st["fail"] = True
+                return False, line
+            if st["pos"] >= n:
+                st["eof"] = st["fail"] = True
+                return False, b""
+            nl = data.find(b"\n", st["pos"])
+            if nl < 0:
+                line, st["pos"], st["eof"] = data[st["pos"]:], n, True
+            else:
+                line, st["pos"] = data[st["pos"]:nl], nl + 1
+            return True, line
+
+        def tellg():
+            if st["eof"] or st["fail"]:
+                st["fail"] = True
+                return -1
+            return st["pos"]
+
+        def seekg(p):
+            st["eof"] = False
+            if not st["fail"]:
+                st["pos"] = p
+
+        props = []
+        fmt = b""
+        line = b""
+        oldpos = tellg()
+        while True:
+            ok, line = getline(line)
+            if not ok:
+                break
+            if line.startswith(b"format"):
+                fmt = line
+            if line.startswith(b"element"):  # LoadElement, ply.cpp:121-158
+                seekg(oldpos)
+                old2 = tellg()
+                ok2, eline = getline(b"")
+                t = _tok(eline)
+                name = t[1] if len(t) > 1 else (t[0] if t else b"")
+                cnt = t[2] if len(t) > 2 else name
+                el = {"name": name.decode("latin-1"), "num_of_elements": max(_atoi(cnt.decode("latin-1")), 0), "num_of_property": 0}
+                pl = []
+                old2 = tellg()
+                while True:
+                    ok2, eline = getline(eline)
+                    if not ok2:
+                        break
+                    t = _tok(eline)
+                    if not t or t[0] != b"property":
+                        break
+                    el["num_of_property"] += 1
+                    pl.append([x.decode("latin-1") for x in t[1:]])
+                    old2 = tellg()
+                seekg(old2)
+                self.elements.append(el)
+                props.append(pl)
+            if line.startswith(b"end_header"):
+                break
+            oldpos = tellg()
+        pos = st["pos"]
+        if len(self.elements) < 2:
+            self.error = "ply header declares fewer than two elements"
+            return False
+        self.binary = b"binary" in fmt
+        if b"binary_big_endian" in fmt:
+            self.error = "binary_big_endian ply files are not supported"
+            return False
+        nv, nf = self.elements[0]["num_of_elements"], self.elements[1]["num_of_elements"]
+        if self.binary:
+            return self._load_binary(data, pos, props, nv, nf)
+        if st["eof"] or st["fail"]:
+            body, filler = [], line  # every further getline fails and leaves the last header line in place
+        else:
+            body = data[pos:].split(b"\n")
+            if body[-1] == b"":
+                body, filler = body[:-1], b""  # the first getline past the end erases the line, the others leave it empty
+            else:
+                filler = body[-1]  # no newline after the last line: further getlines fail without touching the line
+        if len(body) < nv + nf:
+            body = body + [filler] * (nv + nf - len(body))
+        self.vertices = self._ascii_vertices(body[:nv])
+        ok = self._ascii_faces(body[nv:nv + nf])
+        return ok
+
+    @staticmethod
+    def _ascii_vertices(lines):
+        nv = len(lines)
+        out = np.zeros((nv, 6))
+        if nv == 0:
+            return out
+        counts = np.fromiter((len(_tok(l)) for l in lines), dtype=np.int64, count=nv)
+        c = int(counts[0])
+        if c > 0 and bool((counts == c).all()):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                try:
+                    arr = np.fromstring(b" ".join(lines).decode("latin-1"), dtype=np.float64, sep=" ")
+                except (ValueError, DeprecationWarning):
+                    arr = np.zeros(0)
+            if arr.size == nv * c:
+                arr = arr.reshape(nv, c)
+                k = min(c, 6)
+                out[:, :k] = arr[:, :k]
+                out[:, k:] = arr[:, k - 1:k]  # a missing token repeats the last one read
+                return out
+        for i, l in enumerate(lines):  # exact token rules, line by line
+            s = ""
+            t = _tok(l)
+            for j in range(6):
+                if j < len(t):
+                    s = t[j].decode("latin-1")
+                out[i, j] = _atof(s) if s else 0.0
+        return out
+
+    def _ascii_faces(self, lines):
+        nf = len(lines)
+        if nf == 0:
+            return True
+        counts = np.fromiter((len(_tok(l)) for l in lines), dtype=np.int64, count=nf)
+        c = int(counts[0])
+        if c > 1 and bool((counts == c).all()):
+            try:
+                arr = np.array(b" ".join(lines).split(), dtype=np.int64)
+            except (ValueError, OverflowError):
+                arr = np.zeros(0, dtype=np.int64)
+            if arr.size == nf * c:
+                arr = arr.reshape(nf, c)
+                if bool((arr[:, 0] == c - 1).all()):
+                    self.face_index = arr[:, 1:].astype(np.int32).reshape(-1)
+                    self.face_begin = (np.arange(nf + 1, dtype=np.uint64) * np.uint64(c - 1))
+                    return True
+        idx, begin = [], [0]
+        for i, l in enumerate(lines):
+            t = _tok(l)
+            s = t[0].decode("latin-1") if t else ""
+            cnt = _atoi(s) if s else 0
+            if cnt < 0:
+                self.error = "negative corner count in face %d" % i
+                return False
+            for j in range(cnt):
+                if 1 + j < len(t):
+                    s = t[1 + j].decode("latin-1")
+                idx.append(_atoi(s) if s else 0)
+            begin.append(len(idx))
+        self.face_index = np.asarray(idx, dtype=np.int32)
+        self.face_begin = np.asarray(begin, dtype=np.uint64)
+        return True
+
+    def _load_binary(self, data, pos, props, nv, nf):
+        vt = []
+        for k, pr in enumerate(props[0]):
+            if pr[0] == "list" or pr[0] not in _PLY_TYPES:
+                self.error = "unsupported vertex property in binary ply"
+                return False
+            vt.append(("p%d" % k, _PLY_TYPES[pr[0]]))
+        vdt = np.dtype(vt)
+        if pos + nv * vdt.itemsize > len(data):
+            self.error = "binary ply file ends before its declared elements do"
+            return False
+        rec = np.frombuffer(data, dtype=vdt, count=nv, offset=pos)
+        self.vertices = np.zeros((nv, 6))
+        for k in range(min(6, len(vt))):
+            self.vertices[:, k] = rec["p%d" % k]
+        pos += nv * vdt.itemsize
+        fp = props[1]
+        if not fp or fp[0][0] != "list" or any(p[0] == "list" for p in fp[1:]) or any(p[0] not in _PLY_TYPES for p in fp[1:]):
+            self.error = "unsupported face properties in binary ply"
+            return False
+        ct, it = np.dtype(_PLY_TYPES[fp[0][1]]), np.dtype(_PLY_TYPES[fp[0][2]])
+        tail = sum(np.dtype(_PLY_TYPES[p[0]]).itemsize for p in fp[1:])
+        idx, begin = [], [0]
+        total = 0
+        for _ in range(nf):
+            if pos + ct.itemsize > len(data):
+                self.error = "binary ply file ends before its declared elements do"
+                return False
+            c = int(np.frombuffer(data, dtype=ct, count=1, offset=pos)[0])
+            pos += ct.itemsize
+            if pos + c * it.itemsize + tail > len(data):
+                self.error = "binary ply file ends before its declared elements do"
+                return False
+            idx.append(np.frombuffer(data, dtype=it, count=c, offset=pos).astype(np.int32))
+            pos += c * it.itemsize + tail
+            total += c
+            begin.append(total)
+        self.face_index = np.concatenate(idx) if idx else np.zeros(0, dtype=np.int32)
+        self.face_begin = np.asarray(begin, dtype=np.uint64)
+        return True
+
+    # ---- bridge: one object, one polygon per face (rules of ObjModel, object.cpp:94-140; the reference's own
+    # PlyModel is commented out, object.cpp:153-233)
+    def to_mesh(self, name="ply", normals="auto", into=None):
+        """normals: "file" (columns 3..5), "flat" (one per face: (v1-v0)x(v2-v1)), "smooth" (per vertex, sum of the
+        area-weighted face normals), "auto" = "file" when the file has them, else "smooth".  Faces with fewer than
+        three corners or indices outside the vertex table are dropped (count in mesh["dropped_faces"]).
+        `into`: a mesh to append this object to."""
+        if normals == "auto":
+            normals = "file" if self.has_normals() else "smooth"
+        nv = len(self.vertices)
+        fb = self.face_begin.astype(np.int64)
+        fi = self.face_index.astype(np.int64)
+        sizes = np.diff(fb)
+        bad_corner = (fi < 0) | (fi >= nv)
+        bad = np.add.reduceat(bad_corner, fb[:-1][sizes > 0]) > 0 if len(fi) else np.zeros(0, dtype=bool)
+        valid = sizes >= 3
+        if len(fi):
+            tmp = np.zeros(len(sizes), dtype=bool)
+            tmp[sizes > 0] = bad
+            valid &= ~tmp
+        keep_corner = np.repeat(valid, sizes)
+        kfi = fi[keep_corner]
+        ksizes = sizes[valid]
+        kbegin = np.concatenate([[0], np.cumsum(ksizes)])
+        pos = self.vertices[:, 0:3]
+        a, b, c = pos[kfi[kbegin[:-1]]], pos[kfi[kbegin[:-1] + 1]], pos[kfi[kbegin[:-1] + 2]]
+        e0, e1 = b - a, c - b
+        fn = np.stack([e0[:, 1] * e1[:, 2] - e0[:, 2] * e1[:, 1], -(e0[:, 0] * e1[:, 2] - e0[:, 2] * e1[:, 0]),
+                       e0[:, 0] * e1[:, 1] - e0[:, 1] * e1[:, 0]], 1)
+        if normals == "file":
+            vn, corner_n = self.vertices[:, 3:6].copy(), kfi
+        elif normals == "flat":
+            vn, corner_n = fn, np.repeat(np.arange(len(ksizes), dtype=np.int64), ksizes)
+        elif normals == "smooth":
+            w = np.repeat(fn, ksizes, axis=0)
+            vn = np.stack([np.bincount(kfi, weights=w[:, k], minlength=nv) for k in range(3)], 1)
+            zero = (vn == 0).all(1)
+            vn[zero] = [0.0, 0.0, 1.0]
+            corner_n = kfi
+        else:
+            raise ValueError("normals must be auto, file, flat or smooth")
+        v0 = 0 if into is None else len(into["v"])
+        n0 = 0 if into is None else len(into["vn"])
+        corners = np.stack([kfi + v0, np.full(len(kfi), -1, dtype=np.int64), corner_n + n0], 1)
+        mesh = {"v": pos.copy(), "vt": np.zeros((0, 3)), "vn": vn, "corners": corners, "face_begin": kbegin.astype(np.uint64),
+                "object_begin": np.array([0, len(ksizes)], dtype=np.uint64), "names": [name], "dropped_faces": int((~valid).sum())}
+        if into is None:
+            return mesh
+        nf0, nc0 = len(into["face_begin"]) - 1, len(into["corners"])
+        return {"v": np.concatenate([into["v"], mesh["v"]]), "vt": into["vt"], "vn": np.concatenate([into["vn"], vn]),
+                "corners": np.concatenate([into["corners"], corners]),
+                "face_begin": np.concatenate([into["face_begin"], (kbegin[1:] + nc0).astype(np.uint64)]),
+                "object_begin": np.concatenate([into["object_begin"], np.array([nf0 + len(ksizes)], dtype=np.uint64)]),
+                "names": list(into["names"]) + [name], "dropped_faces": into.get("dropped_faces", 0) + mesh["dropped_faces"]}
+
+
+def write_ply(path, vertices, faces, normals=None, binary=False):
+    """Writes an ASCII (or binary little-endian) PLY: vertices [n, 3], optional normals [n, 3], faces = list of index lists
+    or an [m, k] array.  Used for synthetic test and benchmark scenes."""
+    vertices = np.asarray(vertices, dtype=np.float64)
+    uniform = isinstance(faces, np.ndarray) and faces.ndim == 2
+    nfaces = len(faces)
+    head = ["ply", "format %s 1.0" % ("binary_little_endian" if binary else "ascii"), "element vertex %d" % len(vertices)]
+    head += ["property %s %s" % ("double" if binary else "float", c) for c in ("x", "y", "z")]
+    if normals is not None:
+        head += ["property %s %s" % ("double" if binary else "float", c) for c in ("nx", "ny", "nz")]
+    head += ["element face %d" % nfaces, "property list uchar int vertex_indices", "end_header"]
+    cols = vertices if normals is None else np.concatenate([vertices, np.asarray(normals, dtype=np.float64)], 1)
+    with open(path, "wb") as f:
+        f.write(("\n".join(head) + "\n").encode())
+        if binary:
+            f.write(cols.astype("<f8").tobytes())
+            if uniform:
+                rec = np.zeros(nfaces, dtype=[("c", "u1"), ("i", "<i4", (faces.shape[1],))])
+                rec["c"] = faces.shape[1]
+                rec["i"] = faces
+                f.write(rec.tobytes())
+            else:
+                for face in faces:
+                    f.write(bytes([len(face)]) + np.asarray(face, dtype="<i4").tobytes())
+        else:
+            np.savetxt(f, cols, fmt="%.17g")
+            if uniform:
+                np.savetxt(f, np.concatenate([np.full((nfaces, 1), faces.shape[1], dtype=np.int64), faces], 1), fmt="%d")
+            else:
+                for face in faces:
+                    f.write((" ".join([str(len(face))] + [str(int(i)) for i in face]) + "\n").encode())
 
 
 # ----------------------------------------------------------------------------------------------

@@ -259,3 +259,46 @@ def ref_bvh():
     L.ref_world_trace.restype = u64
     L.ref_world_occluded.argtypes = [vp, vp]
     return L
+
+
+def ref_ply():
+    """the reference's own ply.cpp, compiled unmodified (present only where the reference checkout is)"""
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_ply.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    vp, u64 = C.c_void_p, C.c_uint64
+    L.ref_ply_load.argtypes = [C.c_char_p]
+    L.ref_ply_load.restype = vp
+    L.ref_ply_counts.argtypes = [vp] + [C.POINTER(u64)] * 4
+    L.ref_ply_tables.argtypes = [vp, vp, vp, vp]
+    L.ref_ply_element.argtypes = [vp, u64, C.c_char_p, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.ref_ply_free.argtypes = [vp]
+    return L
+
+
+def ref_ply_load(L, path):
+    """(elements, vertices [n, 6], face_begin, face_index) as the compiled reference reads the file"""
+    h = L.ref_ply_load(path.encode())
+    nv, nf, ni, ne = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    L.ref_ply_counts(h, C.byref(nv), C.byref(nf), C.byref(ni), C.byref(ne))
+    vertices = np.zeros((nv.value, 6))
+    face_begin = np.zeros(nf.value + 1, dtype=np.uint64)
+    face_index = np.zeros(ni.value, dtype=np.int32)
+    L.ref_ply_tables(h, _p(vertices), _p(face_begin), _p(face_index))
+    elements = []
+    for k in range(ne.value):
+        name = C.create_string_buffer(256)
+        cnt, npr = C.c_uint64(), C.c_uint64()
+        L.ref_ply_element(h, k, name, 256, C.byref(cnt), C.byref(npr))
+        elements.append({"name": name.value.decode("latin-1"), "num_of_elements": int(cnt.value), "num_of_property": int(npr.value)})
+    L.ref_ply_free(h)
+    return elements, vertices, face_begin, face_index
+
+
+def ply_oracle():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ply_oracle", os.path.join(ROOT, "oracle", "ply_oracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

@@ -237,3 +237,61 @@ def test_deep_tree_uses_the_scratch_stack(ctx):
     o_poly, o_tri, o_t = sc.trace_closest(rays, oracle.MODE_LIST_LOWEST)
     check_closest(hits, t64, o_poly, o_tri, o_t)
     assert (o_poly >= 0).mean() > 0.5
+
+
+def test_unsound_rays_miss_without_walking_the_tree(ctx):
+    """NaN components and zero directions: the exact test can accept nothing (the oracle agrees), and the kernel must
+    not pay a whole-tree walk for them (the conservative box tests accept everything for such rays)"""
+    import time
+    mesh = synth.soup(200000, 0.01, seed=5)
+    sc = oracle.Scene(mesh)
+    ctx.upload_mesh(mesh)
+    rays = synth.incoherent_rays(1 << 18, seed=9)
+    t0 = time.time()
+    ctx.trace_closest(rays)
+    base = time.time() - t0
+    bad = rays.copy()
+    k = np.arange(len(bad))
+    bad[k % 4 == 0, 4] = np.nan
+    bad[k % 4 == 1, 1] = np.nan
+    bad[k % 4 == 2, 4:7] = 0.0
+    bad[k % 4 == 3, 3] = np.nan
+    t0 = time.time()
+    hits, t64 = ctx.trace_closest(bad, want_t64=True)
+    took = time.time() - t0
+    assert (hits["prim"] == capi.MISS).all() and np.isinf(t64).all()
+    assert took < 20 * base + 0.5, (took, base)  # a whole-tree walk per ray would take minutes
+    o_poly, o_tri, o_t = sc.trace_closest(bad[:3000], oracle.MODE_LIST_LOWEST)
+    assert (o_poly == -1).all()
+    assert not ctx.trace_any(bad[:3000]).any() and not sc.trace_any(bad[:3000], oracle.MODE_LIST).any()
+
+
+def test_axis_parallel_rays_are_pruned_like_any_other(ctx):
+    """rays that do not move along one or two axes (mirror bounces off axis-aligned walls produce them) must still be
+    culled by the boxes on those axes: same answers as brute force, and no whole-tree walks"""
+    import time
+    mesh = synth.soup(200000, 0.01, seed=5)
+    sc = oracle.Scene(mesh)
+    ctx.upload_mesh(mesh)
+    rays = synth.incoherent_rays(1 << 18, seed=9)
+    t0 = time.time()
+    ctx.trace_closest(rays)
+    base = time.time() - t0
+    ax = rays.copy()
+    k = np.arange(len(ax))
+    for a in range(3):
+        sel = k % 6 == a
+        ax[sel, 4:7] = 0.0
+        ax[sel, 4 + a] = np.where(k[sel] % 12 < 6, 1.0, -1.0)          # along one axis
+        sel2 = k % 6 == 3 + a
+        ax[sel2, 4 + a] = np.where(k[sel2] % 12 < 6, 0.0, -0.0)         # in an axis plane
+    ax[k % 50 == 0, 4] = 1e-30                                           # inverse overflows in fp32
+    ax[:, 0:3] = np.round(ax[:, 0:3] * 64) / 64                          # origins on round coordinates: box planes are met exactly
+    t0 = time.time()
+    hits, t64 = ctx.trace_closest(ax, want_t64=True)
+    took = time.time() - t0
+    assert took < 5 * base + 0.2, (took, base)
+    n = 4000
+    o_poly, o_tri, o_t = sc.trace_closest(ax[:n], oracle.MODE_LIST_LOWEST)
+    check_closest(hits[:n], t64[:n], o_poly, o_tri, o_t, allow_ties=False)
+    assert 0.3 < (o_poly >= 0).mean()
