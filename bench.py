@@ -133,6 +133,10 @@ def soup_leg(args, ctx, capi, synth, oracle, torch, rank, log):
            "kernel_ms_per_launch": prof["ms"] / reps, "mrays_per_s": m * reps / (prof["ms"] * 1e-3) / 1e6,
            "hit_rate": float((d_hits[:, 1] != -1).float().mean().item()), "bvh_build_s": st["bvh_build_seconds"],
            "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"]}
+    # the host-buffer entry point (rt_trace_closest: rays and hits cross PCIe), for the record only
+    t0 = time.perf_counter()
+    ctx.trace_closest(rays)
+    res["host_buffer_mrays_per_s"] = m / (time.perf_counter() - t0) / 1e6
     if oracle is not None:
         sc = oracle.Scene(mesh)
         nodes, tri_index = ctx.bvh2()
