@@ -7,6 +7,7 @@ import numpy as np
 NBINS = 30
 MISS = 0xFFFFFFFF
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NO_LIGHTS, ERR_NO_MATERIAL, ERR_MESH = 0, -1, -2, -3, -4, -5, -6
+BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH, BUILDER_AUTO = 0, 1, 2
 MAT_NONE, MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_COLORED_METAL = range(6)
 ALG_NAIVE, ALG_NEE, ALG_MIS = 0, 1, 2
 
@@ -14,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libm
 
 # every symbol include/mi355rt.h declares
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_upload_materials", "rt_set_camera", "rt_clear",
+    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_upload_materials", "rt_set_camera", "rt_clear",
     "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
     "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
     "rt_get_stats", "rt_get_bvh2", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
@@ -87,6 +88,7 @@ def load():
     lib.rt_last_error.argtypes = [vp]
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_upload_mesh.argtypes = [vp, C.POINTER(Mesh)]
+    lib.rt_set_builder.argtypes = [vp, C.c_int]
     lib.rt_upload_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32]
     lib.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
     lib.rt_clear.argtypes = [vp]
@@ -152,6 +154,10 @@ class Context:
         ob = np.ascontiguousarray(mesh["object_begin"], dtype=np.uint64)
         m = Mesh(_ptr(v), len(v), _ptr(vt), len(vt), _ptr(vn), len(vn), _ptr(corners), _ptr(fb), len(fb) - 1, _ptr(ob), len(ob) - 1)
         self._check(self.lib.rt_upload_mesh(self.h, C.byref(m)))
+
+    def set_builder(self, builder):
+        """BUILDER_HOST_SAH (default) or BUILDER_DEVICE_LBVH for the next upload_mesh"""
+        self._check(self.lib.rt_set_builder(self.h, int(builder)))
 
     def upload_materials(self, materials):
         """materials: list of dicts {type, light_flag, a, b}, one per obj object."""

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "context.h"
+#include "device_build.h"
 #include "trace.h"
 
 using namespace mi355rt;
@@ -117,30 +118,79 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	ctx->has_materials = false;
 	std::string err;
 	if (!ctx->host.build(*mesh, err)) return set_err(ctx, RT_ERR_MESH, err);
-	BvhBuildOptions opt;
-	if (const char *s = std::getenv("MI355RT_MAX_LEAF")) opt.max_leaf = std::atoi(s);
-	build_bvh(ctx->host, opt, ctx->bvh, ctx->wide);
 	const HostScene &hs = ctx->host;
 	const uint64_t nt = hs.n_tris;
-	// leaf-ordered fp64 triangle records
+	int builder = ctx->builder;
+	if (const char *s = std::getenv("MI355RT_BUILDER")) builder = std::strcmp(s, "device") == 0 ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
+	if (builder == RT_BUILDER_AUTO) builder = nt > 2000000 ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
+	if (nt < 2) builder = RT_BUILDER_HOST_SAH; // the radix tree needs two leaves
+	// fp64 triangle records: v0 + face normal, v1 + v2 (fan order)
 	std::vector<double> tri_a(6 * std::max<uint64_t>(nt, 1), 0.0), tri_b(6 * std::max<uint64_t>(nt, 1), 0.0);
-	std::vector<uint32_t> tri_leaf(nt);
-	for (uint64_t li = 0; li < nt; li++) {
-		const uint32_t t = ctx->wide.tri_index[li];
-		tri_leaf[t] = (uint32_t)li;
+	auto fill_record = [&](uint64_t slot, uint32_t t) {
 		const double *v0, *v1, *v2;
 		hs.tri_vertices(t, v0, v1, v2);
 		const double *fn = &hs.face_normal[3 * (size_t)hs.tri_face[t]];
-		double *a = &tri_a[6 * li], *b = &tri_b[6 * li];
+		double *a = &tri_a[6 * slot], *b = &tri_b[6 * slot];
 		a[0] = v0[0]; a[1] = v0[1]; a[2] = v0[2]; a[3] = fn[0]; a[4] = fn[1]; a[5] = fn[2];
 		b[0] = v1[0]; b[1] = v1[1]; b[2] = v1[2]; b[3] = v2[0]; b[4] = v2[1]; b[5] = v2[2];
-	}
-	if (!dev_upload(ctx, ctx->d_nodes, ctx->wide.nodes) || !dev_upload(ctx, ctx->d_tri_a, tri_a) || !dev_upload(ctx, ctx->d_tri_b, tri_b) ||
-	    !dev_upload(ctx, ctx->d_leaf_tri, ctx->wide.tri_index) || !dev_upload(ctx, ctx->d_tri_face, hs.tri_face) ||
-	    !dev_upload(ctx, ctx->d_face_object, hs.face_object)) {
-		std::string keep = ctx->error;
-		ctx->free_geometry();
-		return set_err(ctx, RT_ERR_HIP, keep);
+	};
+	std::vector<uint32_t> tri_leaf(nt);
+	if (builder == RT_BUILDER_DEVICE_LBVH) {
+		// records go up in fan order; the device builds the tree and reorders them
+		for (uint64_t t = 0; t < nt; t++) fill_record(t, (uint32_t)t);
+		void *d_a = nullptr, *d_b = nullptr;
+		DeviceBvh built;
+		const uint64_t bytes_before = ctx->device_bytes;
+		bool ok = dev_upload(ctx, d_a, tri_a) && dev_upload(ctx, d_b, tri_b);
+		if (ok && build_bvh_device((const double *)d_a, (const double *)d_b, (uint32_t)nt, ctx->stream, built, err) != hipSuccess) {
+			ctx->error = err;
+			ok = false;
+		}
+		if (d_a) (void)hipFree(d_a);
+		if (d_b) (void)hipFree(d_b);
+		ctx->device_bytes = bytes_before; // the fan-order copies are gone again
+		if (ok) {
+			ctx->d_nodes = built.nodes;
+			ctx->d_tri_a = built.tri_a;
+			ctx->d_tri_b = built.tri_b;
+			ctx->d_leaf_tri = built.leaf_tri;
+			ctx->device_bytes += (uint64_t)built.n_nodes * sizeof(WideNode) + nt * (96 + 4);
+			ctx->bvh = Bvh2();
+			ctx->wide = BvhWide();
+			ctx->wide.depth = built.depth;
+			ctx->wide.tri_index.resize(nt);
+			ctx->bvh.build_seconds = built.seconds;
+			ctx->bvh.depth = built.depth;
+			ctx->built_on_device = true;
+			ctx->device_nodes = built.n_nodes;
+			ok = !ctx->fail_hip(hipMemcpy(ctx->wide.tri_index.data(), built.leaf_tri, nt * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy(leaf order)") &&
+			     !ctx->fail_hip(hipMemcpy(tri_leaf.data(), built.tri_leaf, nt * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy(triangle positions)");
+			(void)hipFree(built.tri_leaf);
+		}
+		ok = ok && dev_upload(ctx, ctx->d_tri_face, hs.tri_face) && dev_upload(ctx, ctx->d_face_object, hs.face_object);
+		if (!ok) {
+			std::string keep = ctx->error;
+			ctx->free_geometry();
+			return set_err(ctx, RT_ERR_HIP, keep);
+		}
+	} else {
+		BvhBuildOptions opt;
+		if (const char *s = std::getenv("MI355RT_MAX_LEAF")) opt.max_leaf = std::atoi(s);
+		build_bvh(ctx->host, opt, ctx->bvh, ctx->wide);
+		ctx->built_on_device = false;
+		ctx->device_nodes = ctx->wide.nodes.size();
+		for (uint64_t li = 0; li < nt; li++) { // leaf-ordered records
+			const uint32_t t = ctx->wide.tri_index[li];
+			tri_leaf[t] = (uint32_t)li;
+			fill_record(li, t);
+		}
+		if (!dev_upload(ctx, ctx->d_nodes, ctx->wide.nodes) || !dev_upload(ctx, ctx->d_tri_a, tri_a) || !dev_upload(ctx, ctx->d_tri_b, tri_b) ||
+		    !dev_upload(ctx, ctx->d_leaf_tri, ctx->wide.tri_index) || !dev_upload(ctx, ctx->d_tri_face, hs.tri_face) ||
+		    !dev_upload(ctx, ctx->d_face_object, hs.face_object)) {
+			std::string keep = ctx->error;
+			ctx->free_geometry();
+			return set_err(ctx, RT_ERR_HIP, keep);
+		}
 	}
 	ctx->geom.nodes = (const float4 *)ctx->d_nodes;
 	ctx->geom.tri_a = (const double2 *)ctx->d_tri_a;
@@ -153,6 +203,14 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	hipError_t e = render_upload_scene(ctx->render, hs, tri_leaf, ctx->geom.tri_face, ctx->geom.face_object, ctx->stream, err);
 	if (e != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	ctx->has_mesh = true;
+	return RT_OK;
+}
+
+int rt_set_builder(rt_context *ctx, int builder)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	if (builder != RT_BUILDER_HOST_SAH && builder != RT_BUILDER_DEVICE_LBVH && builder != RT_BUILDER_AUTO) return set_err(ctx, RT_ERR_INVALID, "rt_set_builder: unknown builder");
+	ctx->builder = builder;
 	return RT_OK;
 }
 
@@ -329,7 +387,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
 	out->n_triangles = ctx->host.n_tris;
 	out->n_objects = ctx->host.n_objects;
 	out->n_lights = ctx->light_faces.size();
-	out->bvh_nodes = ctx->bvh.nodes.size();
+	out->bvh_nodes = ctx->built_on_device ? ctx->device_nodes : ctx->bvh.nodes.size();
 	out->bvh_depth = ctx->bvh.depth;
 	out->bvh_leaves = ctx->bvh.n_leaves;
 	out->bvh_build_seconds = ctx->bvh.build_seconds;
@@ -344,6 +402,7 @@ int rt_get_bvh2(rt_context *ctx, rt_bvh2_node *nodes, uint64_t *n_nodes, uint32_
 {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_get_bvh2: no mesh uploaded");
+	if (ctx->built_on_device) return set_err(ctx, RT_ERR_INVALID, "rt_get_bvh2: the tree was built on the device; only the host builder keeps a BVH2");
 	if (n_nodes) *n_nodes = ctx->bvh.nodes.size();
 	if (n_tris) *n_tris = ctx->bvh.tri_index.size();
 	if (nodes) std::memcpy(nodes, ctx->bvh.nodes.data(), ctx->bvh.nodes.size() * sizeof(rt_bvh2_node));

@@ -19,6 +19,9 @@ struct rt_context {
 	mi355rt::Bvh2 bvh;     // binary tree, host only: introspection and work counting
 	mi355rt::BvhWide wide; // the tree the device walks
 	bool has_mesh = false, has_materials = false, has_camera = false;
+	int builder = RT_BUILDER_AUTO;
+	bool built_on_device = false;
+	uint64_t device_nodes = 0;     // nodes of the tree in HBM
 
 	// geometry in HBM
 	void *d_nodes = nullptr, *d_tri_a = nullptr, *d_tri_b = nullptr, *d_leaf_tri = nullptr, *d_tri_face = nullptr,

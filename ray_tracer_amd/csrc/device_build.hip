@@ -1,0 +1,525 @@
+// BVH construction on the device: Morton-ordered binary radix tree (one thread per internal node), bottom-up
+// box fit, then a level-by-level collapse into the 8-wide quantised nodes the traversal kernel walks.
+// Stands in for SAHBVHNode::SAHBVHNode (reference bvh.cpp:134-232) when the scene is large: the topology is free
+// to differ from the reference's, because a closest hit does not depend on it (ties in t aside).
+//
+// Stages (n = fan triangles, all buffers in HBM):
+//   k_tri_boxes     fp64 vertices -> fp32 boxes rounded outward, scene bounds of the box centres (ordered-int atomics)
+//   k_morton        63-bit Morton key of each box centre (21 bits per axis)
+//   radix sort      hipcub::DeviceRadixSort (key, triangle id)
+//   k_hierarchy     binary radix tree over the sorted keys; ties between equal keys are broken by position
+//   k_fit           leaves walk up; the second thread to reach a node unions its children's boxes
+//   k_collapse      one thread per wide node and level: opens the child with the largest area until there are 8,
+//                   assigns slots by octant, quantises the child boxes, reserves its interior children and its leaf
+//                   triangles with one atomic each, and queues the interior children for the next level
+//   k_gather        triangle records into leaf order
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <cfloat>
+#include <chrono>
+#include <cstdint>
+#include <string>
+#include "bvh_builder.h"
+#include "device_build.h"
+
+namespace mi355rt {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kMaxLeaf = 4; // triangles per leaf child: a wide node addresses 8 x 4 = 32 triangles
+constexpr float kCostNode = 1.0f, kCostTri = 1.5f; // surface-area heuristic: one interior step, one triangle test
+
+#define DB_TRY(x)                                                                       \
+	do {                                                                                \
+		hipError_t e_ = (x);                                                            \
+		if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return e_; } \
+	} while (0)
+
+// order-preserving map float -> int, so that integer atomicMin/Max order floats
+__device__ __forceinline__ int float_to_ordered(float f)
+{
+	int i = __float_as_int(f);
+	return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__host__ __device__ inline float ordered_to_float(int i)
+{
+	int j = i >= 0 ? i : i ^ 0x7FFFFFFF;
+#ifdef __HIP_DEVICE_COMPILE__
+	return __int_as_float(j);
+#else
+	float f;
+	memcpy(&f, &j, 4);
+	return f;
+#endif
+}
+
+struct Box4 {
+	float4 lo, hi; // w unused
+};
+
+__global__ void __launch_bounds__(kBlock) k_tri_boxes(const double2 *__restrict__ tri_a, const double2 *__restrict__ tri_b, uint32_t n,
+                                                      Box4 *__restrict__ boxes, int *__restrict__ bounds)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+	if (i < n) {
+		const double2 a0 = tri_a[3 * (size_t)i], a1 = tri_a[3 * (size_t)i + 1];
+		const double2 b0 = tri_b[3 * (size_t)i], b1 = tri_b[3 * (size_t)i + 1], b2 = tri_b[3 * (size_t)i + 2];
+		const double vx[3] = {a0.x, b0.x, b1.y}, vy[3] = {a0.y, b0.y, b2.x}, vz[3] = {a1.x, b1.x, b2.y};
+		Box4 b;
+		b.lo = make_float4(__double2float_rd(fmin(fmin(vx[0], vx[1]), vx[2])), __double2float_rd(fmin(fmin(vy[0], vy[1]), vy[2])),
+		                   __double2float_rd(fmin(fmin(vz[0], vz[1]), vz[2])), 0.0f);
+		b.hi = make_float4(__double2float_ru(fmax(fmax(vx[0], vx[1]), vx[2])), __double2float_ru(fmax(fmax(vy[0], vy[1]), vy[2])),
+		                   __double2float_ru(fmax(fmax(vz[0], vz[1]), vz[2])), 0.0f);
+		boxes[i] = b;
+		clo[0] = chi[0] = 0.5f * (b.lo.x + b.hi.x);
+		clo[1] = chi[1] = 0.5f * (b.lo.y + b.hi.y);
+		clo[2] = chi[2] = 0.5f * (b.lo.z + b.hi.z);
+	}
+	// wave reduction, then one atomic per wave and component
+	for (int a = 0; a < 3; a++) {
+		float lo = clo[a], hi = chi[a];
+		for (int off = 32; off > 0; off >>= 1) {
+			lo = fminf(lo, __shfl_xor(lo, off));
+			hi = fmaxf(hi, __shfl_xor(hi, off));
+		}
+		if ((threadIdx.x & 63) == 0 && lo <= hi) {
+			atomicMin(&bounds[a], float_to_ordered(lo));
+			atomicMax(&bounds[3 + a], float_to_ordered(hi));
+		}
+	}
+}
+
+__device__ __forceinline__ uint64_t spread21(uint64_t x)
+{
+	x &= 0x1FFFFFull;
+	x = (x | (x << 32)) & 0x1F00000000FFFFull;
+	x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+	x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+	x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+	x = (x | (x << 2)) & 0x1249249249249249ull;
+	return x;
+}
+
+__global__ void __launch_bounds__(kBlock) k_morton(const Box4 *__restrict__ boxes, uint32_t n, const int *__restrict__ bounds,
+                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const Box4 b = boxes[i];
+	const float c[3] = {0.5f * (b.lo.x + b.hi.x), 0.5f * (b.lo.y + b.hi.y), 0.5f * (b.lo.z + b.hi.z)};
+	uint64_t q[3];
+	for (int a = 0; a < 3; a++) {
+		const float lo = ordered_to_float(bounds[a]), hi = ordered_to_float(bounds[3 + a]);
+		const float ext = hi - lo;
+		float u = ext > 0.0f ? (c[a] - lo) / ext : 0.0f;
+		u = fminf(fmaxf(u, 0.0f), 1.0f);
+		q[a] = (uint64_t)fminf(u * 2097152.0f, 2097151.0f);
+	}
+	keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+	vals[i] = i;
+}
+
+// Binary radix tree.  Internal node i in [0, n-1), leaf j in [0, n) = position in the sorted order.
+// Child links: >= 0 internal node, < 0 leaf ~position.
+struct BinNode {
+	int32_t left, right;
+	uint32_t first, last; // range of sorted positions under this node
+};
+
+__device__ __forceinline__ int delta(const uint64_t *__restrict__ keys, int n, int i, int j)
+{
+	if (j < 0 || j >= n) return -1;
+	const uint64_t k = keys[i] ^ keys[j];
+	if (k == 0) return 64 + __clz((unsigned)(i ^ j));
+	return __clzll((long long)k);
+}
+
+__global__ void __launch_bounds__(kBlock) k_hierarchy(const uint64_t *__restrict__ keys, int n, BinNode *__restrict__ nodes,
+                                                      int32_t *__restrict__ parent_of_node, int32_t *__restrict__ parent_of_leaf)
+{
+	const int i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n - 1) return;
+	const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+	const int dmin = delta(keys, n, i, i - d);
+	int lmax = 2;
+	while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+	int l = 0;
+	for (int t = lmax >> 1; t >= 1; t >>= 1)
+		if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+	const int j = i + l * d;
+	const int dnode = delta(keys, n, i, j);
+	int s = 0, t = l;
+	do {
+		t = (t + 1) >> 1;
+		if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+	} while (t > 1);
+	const int gamma = i + s * d + min(d, 0);
+	const int lo = min(i, j), hi = max(i, j);
+	BinNode nd;
+	nd.first = (uint32_t)lo;
+	nd.last = (uint32_t)hi;
+	if (lo == gamma) { nd.left = ~gamma; parent_of_leaf[gamma] = i; }
+	else { nd.left = gamma; parent_of_node[gamma] = i; }
+	if (hi == gamma + 1) { nd.right = ~(gamma + 1); parent_of_leaf[gamma + 1] = i; }
+	else { nd.right = gamma + 1; parent_of_node[gamma + 1] = i; }
+	nodes[i] = nd;
+	if (i == 0) parent_of_node[0] = -1;
+}
+
+__device__ __forceinline__ Box4 box_union(const Box4 &a, const Box4 &b)
+{
+	Box4 r;
+	r.lo = make_float4(fminf(a.lo.x, b.lo.x), fminf(a.lo.y, b.lo.y), fminf(a.lo.z, b.lo.z), 0.0f);
+	r.hi = make_float4(fmaxf(a.hi.x, b.hi.x), fmaxf(a.hi.y, b.hi.y), fmaxf(a.hi.z, b.hi.z), 0.0f);
+	return r;
+}
+
+__device__ __forceinline__ float half_area(const Box4 &b)
+{
+	const float dx = b.hi.x - b.lo.x, dy = b.hi.y - b.lo.y, dz = b.hi.z - b.lo.z;
+	return dx * dy + dy * dz + dz * dx;
+}
+
+// Leaves walk up; the second thread to reach a node unions its children's boxes.  On the way the surface-area cost of
+// each subtree is settled bottom up: a subtree of at most kMaxLeaf triangles becomes one leaf child of a wide node when
+// testing all its triangles is estimated cheaper than descending further (same constants as the host builder).
+__global__ void __launch_bounds__(kBlock) k_fit(const BinNode *__restrict__ nodes, const int32_t *__restrict__ parent_of_node,
+                                                const int32_t *__restrict__ parent_of_leaf, const Box4 *__restrict__ tri_boxes,
+                                                const uint32_t *__restrict__ sorted_tri, int n, Box4 *node_boxes, float *node_cost,
+                                                uint8_t *__restrict__ as_leaf, unsigned int *__restrict__ arrived)
+{
+	const int leaf = blockIdx.x * kBlock + threadIdx.x;
+	if (leaf >= n) return;
+	int node = parent_of_leaf[leaf];
+	while (node >= 0) {
+		__threadfence(); // the boxes written below this node must be visible to whoever arrives second
+		if (atomicAdd(&arrived[node], 1u) == 0u) return; // first to arrive: the sibling subtree is not finished yet
+		__threadfence();
+		const BinNode nd = nodes[node];
+		// the fence above is the acquire side: the sibling's box, written on another CU before its own fence and
+		// counter increment, is read from L2, not from a stale line of this CU's vector cache
+		const Box4 a = nd.left >= 0 ? node_boxes[nd.left] : tri_boxes[sorted_tri[~nd.left]];
+		const Box4 b = nd.right >= 0 ? node_boxes[nd.right] : tri_boxes[sorted_tri[~nd.right]];
+		const float ca = nd.left >= 0 ? node_cost[nd.left] : kCostTri * half_area(a);
+		const float cb = nd.right >= 0 ? node_cost[nd.right] : kCostTri * half_area(b);
+		const Box4 u = box_union(a, b);
+		const uint32_t count = nd.last - nd.first + 1u;
+		const float split = kCostNode * half_area(u) + ca + cb, whole = kCostTri * (float)count * half_area(u);
+		const bool leaf_wins = count <= kMaxLeaf && whole <= split;
+		node_boxes[node] = u;
+		node_cost[node] = leaf_wins ? whole : split;
+		as_leaf[node] = leaf_wins ? 1 : 0;
+		node = parent_of_node[node];
+	}
+}
+
+// smallest e with 2^e * 255 >= extent (the cell size of a wide node on one axis), clamped to the float exponent range
+__device__ __forceinline__ int cell_exponent(double extent)
+{
+	if (!(extent > 0.0)) return -126;
+	int e;
+	const double f = frexp(extent / 255.0, &e); // extent / 255 = f * 2^e, f in [0.5, 1)
+	if (f == 0.5) e -= 1;
+	while (ldexp(1.0, e) * 255.0 < extent) e++;
+	return max(-126, min(127, e));
+}
+
+struct Counters {
+	unsigned int nodes;     // wide nodes handed out
+	unsigned int tris;      // leaf-order positions handed out
+	unsigned int queue_out; // entries appended to the next level's queue
+	unsigned int overflow;  // a node needed more than 32 leaf triangles (cannot happen with kMaxLeaf 4)
+};
+
+// one thread per wide node of the current level; queue entries: x = binary node (or ~position of a single leaf for
+// a one-triangle scene), y = index of the wide node to fill
+__global__ void __launch_bounds__(kBlock) k_collapse(const BinNode *__restrict__ bin, const Box4 *__restrict__ node_boxes, const uint8_t *__restrict__ as_leaf,
+                                                     const Box4 *__restrict__ tri_boxes, const uint32_t *__restrict__ sorted_tri,
+                                                     const uint2 *__restrict__ queue_in, uint32_t n_in, uint2 *__restrict__ queue_out,
+                                                     WideNode *__restrict__ wide, uint32_t *__restrict__ leaf_tri, Counters *__restrict__ ctr)
+{
+	const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
+	if (qi >= n_in) return;
+	const uint2 job = queue_in[qi];
+	// ---- pick up to 8 children: open the interior child with the largest area until full
+	int32_t kids[8];
+	Box4 kb[8];
+	bool interior[8];
+	int nk = 0;
+	auto add = [&](int32_t link) {
+		kids[nk] = link;
+		if (link >= 0) {
+			kb[nk] = node_boxes[link];
+			interior[nk] = as_leaf[link] == 0;
+		} else {
+			kb[nk] = tri_boxes[sorted_tri[~link]];
+			interior[nk] = false;
+		}
+		nk++;
+	};
+	{
+		const BinNode root = bin[job.x];
+		add(root.left);
+		add(root.right);
+	}
+	while (nk < 8) {
+		int best = -1;
+		float best_area = -1.0f;
+		for (int i = 0; i < nk; i++) {
+			if (!interior[i]) continue;
+			const float dx = kb[i].hi.x - kb[i].lo.x, dy = kb[i].hi.y - kb[i].lo.y, dz = kb[i].hi.z - kb[i].lo.z;
+			const float area = dx * dy + dy * dz + dz * dx;
+			if (area > best_area) { best_area = area; best = i; }
+		}
+		if (best < 0) break;
+		const BinNode open = bin[kids[best]];
+		// the opened child's place is taken by its left child, the right child is appended
+		const int keep = nk;
+		nk = best;
+		add(open.left);
+		nk = keep;
+		add(open.right);
+	}
+	// ---- node box and cell sizes
+	Box4 box = kb[0];
+	for (int i = 1; i < nk; i++) box = box_union(box, kb[i]);
+	WideNode nd;
+	{
+		uint4 *z = reinterpret_cast<uint4 *>(&nd);
+		for (int i = 0; i < 8; i++) z[i] = make_uint4(0, 0, 0, 0);
+	}
+	const float blo[3] = {box.lo.x, box.lo.y, box.lo.z}, bhi[3] = {box.hi.x, box.hi.y, box.hi.z};
+	double scale[3];
+	for (int a = 0; a < 3; a++) {
+		nd.org[a] = blo[a];
+		const int e = cell_exponent((double)bhi[a] - (double)blo[a]);
+		nd.e[a] = (uint8_t)(e + 127);
+		scale[a] = ldexp(1.0, e);
+	}
+	// ---- slots: the octant of the child's centre relative to the node's centre; children far from the centre choose first
+	int child_in_slot[8];
+	for (int sl = 0; sl < 8; sl++) child_in_slot[sl] = -1;
+	float dist[8];
+	int want[8];
+	for (int i = 0; i < nk; i++) {
+		const float clo[3] = {kb[i].lo.x, kb[i].lo.y, kb[i].lo.z}, chi[3] = {kb[i].hi.x, kb[i].hi.y, kb[i].hi.z};
+		float dsum = 0.0f;
+		int w = 0;
+		for (int a = 0; a < 3; a++) {
+			const float c = 0.5f * (clo[a] + chi[a]), m = 0.5f * (blo[a] + bhi[a]);
+			dsum += fabsf(c - m);
+			if (c > m) w |= 1 << a;
+		}
+		dist[i] = dsum;
+		want[i] = w;
+	}
+	uint32_t placed = 0;
+	for (int round = 0; round < nk; round++) {
+		int i = -1;
+		for (int k = 0; k < nk; k++)
+			if (!((placed >> k) & 1u) && (i < 0 || dist[k] > dist[i])) i = k;
+		placed |= 1u << i;
+		int best_slot = -1, best_d = 99;
+		for (int sl = 0; sl < 8; sl++) {
+			if (child_in_slot[sl] >= 0) continue;
+			const int dd = __popc((unsigned)(sl ^ want[i]));
+			if (dd < best_d) { best_d = dd; best_slot = sl; }
+		}
+		child_in_slot[best_slot] = i;
+	}
+	// ---- quantise; count interior children and leaf triangles
+	for (int a = 0; a < 3; a++)
+		for (int sl = 0; sl < 8; sl++) { nd.qlo[a][sl] = 255; nd.qhi[a][sl] = 0; }
+	uint32_t n_interior = 0, n_leaf_tris = 0;
+	for (int sl = 0; sl < 8; sl++) {
+		const int i = child_in_slot[sl];
+		if (i < 0) continue;
+		const float clo[3] = {kb[i].lo.x, kb[i].lo.y, kb[i].lo.z}, chi[3] = {kb[i].hi.x, kb[i].hi.y, kb[i].hi.z};
+		for (int a = 0; a < 3; a++) {
+			double lo = floor(((double)clo[a] - (double)nd.org[a]) / scale[a]);
+			double hi = ceil(((double)chi[a] - (double)nd.org[a]) / scale[a]);
+			lo = fmax(0.0, fmin(255.0, lo));
+			hi = fmax(0.0, fmin(255.0, hi));
+			while ((double)nd.org[a] + lo * scale[a] > (double)clo[a] && lo > 0.0) lo -= 1.0;
+			while ((double)nd.org[a] + hi * scale[a] < (double)chi[a] && hi < 255.0) hi += 1.0;
+			nd.qlo[a][sl] = (uint8_t)lo;
+			nd.qhi[a][sl] = (uint8_t)hi;
+		}
+		if (interior[i]) {
+			nd.imask |= (uint8_t)(1u << sl);
+			n_interior++;
+		} else {
+			n_leaf_tris += kids[i] >= 0 ? bin[kids[i]].last - bin[kids[i]].first + 1u : 1u;
+		}
+	}
+	if (n_leaf_tris > 32u) { atomicAdd(&ctr->overflow, 1u); return; }
+	const uint32_t child_base = n_interior ? atomicAdd(&ctr->nodes, n_interior) : 0u;
+	const uint32_t tri_base = n_leaf_tris ? atomicAdd(&ctr->tris, n_leaf_tris) : 0u;
+	const uint32_t q_base = n_interior ? atomicAdd(&ctr->queue_out, n_interior) : 0u;
+	nd.child_base = child_base;
+	nd.tri_base = tri_base;
+	uint32_t rel = 0, off = 0;
+	for (int sl = 0; sl < 8; sl++) {
+		const int i = child_in_slot[sl];
+		if (i < 0) continue;
+		if (interior[i]) {
+			queue_out[q_base + rel] = make_uint2((uint32_t)kids[i], child_base + rel);
+			rel++;
+		} else {
+			const uint32_t first = kids[i] >= 0 ? bin[kids[i]].first : (uint32_t)~kids[i];
+			const uint32_t count = kids[i] >= 0 ? bin[kids[i]].last - bin[kids[i]].first + 1u : 1u;
+			nd.meta[sl] = (uint8_t)((count << 5) | off);
+			for (uint32_t k = 0; k < count; k++) leaf_tri[tri_base + off + k] = sorted_tri[first + k];
+			off += count;
+		}
+	}
+	uint4 *dst = reinterpret_cast<uint4 *>(&wide[job.y]);
+	const uint4 *src = reinterpret_cast<const uint4 *>(&nd);
+	for (int i = 0; i < 8; i++) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(kBlock) k_gather(const double2 *__restrict__ a_in, const double2 *__restrict__ b_in,
+                                                   const uint32_t *__restrict__ leaf_tri, uint32_t n, double2 *__restrict__ a_out,
+                                                   double2 *__restrict__ b_out, uint32_t *__restrict__ tri_leaf)
+{
+	const uint32_t li = blockIdx.x * kBlock + threadIdx.x;
+	if (li >= n) return;
+	const uint32_t t = leaf_tri[li];
+	for (int k = 0; k < 3; k++) {
+		a_out[3 * (size_t)li + k] = a_in[3 * (size_t)t + k];
+		b_out[3 * (size_t)li + k] = b_in[3 * (size_t)t + k];
+	}
+	tri_leaf[t] = li;
+}
+
+template <class T>
+hipError_t dalloc(T *&p, size_t count, std::vector<void *> &owned)
+{
+	void *q = nullptr;
+	hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+	if (e == hipSuccess) { p = static_cast<T *>(q); owned.push_back(q); }
+	return e;
+}
+
+} // namespace
+
+hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan, uint32_t n, hipStream_t stream, DeviceBvh &out, std::string &err)
+{
+	out = DeviceBvh();
+	if (n < 2) { err = "build_bvh_device: needs at least two triangles"; return hipErrorInvalidValue; }
+	auto t_start = std::chrono::steady_clock::now();
+	std::vector<void *> tmp; // scratch freed on every exit path
+	struct Cleanup {
+		std::vector<void *> &v;
+		~Cleanup() { for (void *p : v) (void)hipFree(p); }
+	} cleanup{tmp};
+	const unsigned blocks_n = (n + kBlock - 1) / kBlock;
+
+	Box4 *tri_boxes = nullptr, *node_boxes = nullptr;
+	int *bounds = nullptr;
+	uint64_t *keys = nullptr, *keys_sorted = nullptr;
+	uint32_t *vals = nullptr, *sorted_tri = nullptr;
+	BinNode *bin = nullptr;
+	int32_t *parent_of_node = nullptr, *parent_of_leaf = nullptr;
+	unsigned int *arrived = nullptr;
+	float *node_cost = nullptr;
+	uint8_t *as_leaf = nullptr;
+	Counters *ctr = nullptr;
+	uint2 *queue[2] = {nullptr, nullptr};
+	DB_TRY(dalloc(tri_boxes, n, tmp));
+	DB_TRY(dalloc(node_boxes, n, tmp));
+	DB_TRY(dalloc(bounds, 6, tmp));
+	DB_TRY(dalloc(keys, n, tmp));
+	DB_TRY(dalloc(keys_sorted, n, tmp));
+	DB_TRY(dalloc(vals, n, tmp));
+	DB_TRY(dalloc(sorted_tri, n, tmp));
+	DB_TRY(dalloc(bin, n, tmp));
+	DB_TRY(dalloc(parent_of_node, n, tmp));
+	DB_TRY(dalloc(parent_of_leaf, n, tmp));
+	DB_TRY(dalloc(arrived, n, tmp));
+	DB_TRY(dalloc(node_cost, n, tmp));
+	DB_TRY(dalloc(as_leaf, n, tmp));
+	DB_TRY(dalloc(ctr, 1, tmp));
+	DB_TRY(dalloc(queue[0], n, tmp));
+	DB_TRY(dalloc(queue[1], n, tmp));
+
+	// ---- boxes, keys, sort
+	const int init_bounds[6] = {0x7F7FFFFF, 0x7F7FFFFF, 0x7F7FFFFF, (int)0x80800000, (int)0x80800000, (int)0x80800000}; // +FLT_MAX x3, ordered(-FLT_MAX) x3
+	DB_TRY(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
+	hipLaunchKernelGGL(k_tri_boxes, dim3(blocks_n), dim3(kBlock), 0, stream, (const double2 *)d_tri_a_fan, (const double2 *)d_tri_b_fan, n, tri_boxes, bounds);
+	hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(kBlock), 0, stream, tri_boxes, n, bounds, keys, vals);
+	size_t sort_bytes = 0;
+	DB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys_sorted, vals, sorted_tri, (int)n, 0, 63, stream));
+	char *sort_tmp = nullptr;
+	DB_TRY(dalloc(sort_tmp, sort_bytes, tmp));
+	DB_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys, keys_sorted, vals, sorted_tri, (int)n, 0, 63, stream));
+
+	// ---- binary tree and its boxes
+	DB_TRY(hipMemsetAsync(arrived, 0, sizeof(unsigned int) * n, stream));
+	hipLaunchKernelGGL(k_hierarchy, dim3(blocks_n), dim3(kBlock), 0, stream, keys_sorted, (int)n, bin, parent_of_node, parent_of_leaf);
+	hipLaunchKernelGGL(k_fit, dim3(blocks_n), dim3(kBlock), 0, stream, bin, parent_of_node, parent_of_leaf, tri_boxes, sorted_tri, (int)n, node_boxes, node_cost, as_leaf, arrived);
+	DB_TRY(hipGetLastError());
+
+	// ---- collapse, level by level.  A wide node has at least two children, so there are at most n - 1 of them.
+	WideNode *wide = nullptr;
+	uint32_t *leaf_tri = nullptr;
+	DB_TRY(dalloc(wide, n, tmp));
+	DB_TRY(dalloc(leaf_tri, n, tmp));
+	Counters h_ctr{1u, 0u, 0u, 0u}; // node 0 = the root
+	DB_TRY(hipMemcpyAsync(ctr, &h_ctr, sizeof(h_ctr), hipMemcpyHostToDevice, stream));
+	const uint2 root_job = make_uint2(0u, 0u);
+	DB_TRY(hipMemcpyAsync(queue[0], &root_job, sizeof(root_job), hipMemcpyHostToDevice, stream));
+	uint32_t n_in = 1, depth = 0;
+	int cur = 0;
+	while (n_in > 0) {
+		depth++;
+		if (depth > 200) { err = "build_bvh_device: tree deeper than 200 levels"; return hipErrorUnknown; }
+		hipLaunchKernelGGL(k_collapse, dim3((n_in + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, bin, node_boxes, as_leaf, tri_boxes, sorted_tri,
+		                   queue[cur], n_in, queue[cur ^ 1], wide, leaf_tri, ctr);
+		DB_TRY(hipMemcpyAsync(&h_ctr, ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, stream));
+		DB_TRY(hipStreamSynchronize(stream));
+		if (h_ctr.overflow) { err = "build_bvh_device: a node holds more than 32 leaf triangles"; return hipErrorUnknown; }
+		n_in = h_ctr.queue_out;
+		DB_TRY(hipMemsetAsync(&ctr->queue_out, 0, sizeof(unsigned int), stream));
+		cur ^= 1;
+	}
+	if (h_ctr.tris != n) { err = "build_bvh_device: leaf order does not cover every triangle"; return hipErrorUnknown; }
+
+	// ---- results: right-sized node array, leaf order, triangle records in leaf order
+	const uint32_t n_nodes = h_ctr.nodes;
+	std::vector<void *> keep;
+	WideNode *nodes_out = nullptr;
+	uint32_t *leaf_out = nullptr, *tri_leaf = nullptr;
+	double2 *a_out = nullptr, *b_out = nullptr;
+	hipError_t e = dalloc(nodes_out, n_nodes, keep);
+	if (e == hipSuccess) e = dalloc(leaf_out, n, keep);
+	if (e == hipSuccess) e = dalloc(tri_leaf, n, keep);
+	if (e == hipSuccess) e = dalloc(a_out, 3 * (size_t)n, keep);
+	if (e == hipSuccess) e = dalloc(b_out, 3 * (size_t)n, keep);
+	if (e == hipSuccess) e = hipMemcpyAsync(nodes_out, wide, sizeof(WideNode) * n_nodes, hipMemcpyDeviceToDevice, stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(leaf_out, leaf_tri, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_gather, dim3(blocks_n), dim3(kBlock), 0, stream, (const double2 *)d_tri_a_fan, (const double2 *)d_tri_b_fan, leaf_tri, n,
+		                   a_out, b_out, tri_leaf);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(stream);
+	if (e != hipSuccess) {
+		for (void *p : keep) (void)hipFree(p);
+		err = std::string("build_bvh_device: ") + hipGetErrorString(e);
+		return e;
+	}
+	out.nodes = nodes_out;
+	out.leaf_tri = leaf_out;
+	out.tri_leaf = tri_leaf;
+	out.tri_a = a_out;
+	out.tri_b = b_out;
+	out.n_nodes = n_nodes;
+	out.depth = depth;
+	out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+	return hipSuccess;
+}
+
+} // namespace mi355rt
