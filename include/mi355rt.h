@@ -142,6 +142,11 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh);
  * environment variable MI355RT_BUILDER=host|device overrides it. */
 typedef enum rt_builder { RT_BUILDER_HOST_SAH = 0, RT_BUILDER_DEVICE_LBVH = 1, RT_BUILDER_AUTO = 2 } rt_builder;
 int rt_set_builder(rt_context *ctx, int builder);
+/* replaces: the globals env_mapping_texture / env_mapping_width / env_mapping_height / env_mapping_bpp / env_brightness
+ * (scene.h:20-22, filled by stbi_load at scene.cpp:245) that NaivePathTracing reads when a ray leaves the scene
+ * (renderer.cpp:175-193).  texels: height rows of width texels, bpp (3 or 4) bytes each, copied; NULL removes the
+ * environment.  Only the naive integrator uses it, as in the reference. */
+int rt_set_environment(rt_context *ctx, const uint8_t *texels, int width, int height, int bpp, double brightness);
 /* replaces: Renderer::LoadMaterials (renderer.cpp:24-44): one record per obj object, in object
  * order; collects the light polygons; RT_ERR_NO_LIGHTS when there is none. */
 int rt_upload_materials(rt_context *ctx, const rt_material *per_object, uint32_t n_objects);

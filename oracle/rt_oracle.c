@@ -429,6 +429,10 @@ struct orc_scene {
 	orc_material *mats; /* per object */
 	uint64_t *lights;   /* polygon ids */
 	uint64_t n_lights;
+	/* environment texture (globals of scene.h:20-22) */
+	uint8_t *env;
+	int env_w, env_h, env_bpp;
+	double env_brightness;
 };
 
 static aabb polygon_bbox(const orc_scene *s, uint64_t p) /* object.cpp:309-328 */
@@ -527,7 +531,7 @@ void orc_scene_free(orc_scene *s)
 	free(s->poly_begin); free(s->tri_begin); free(s->object_begin);
 	free(s->pv); free(s->pvt); free(s->pn); free(s->face_normal); free(s->object_id);
 	free(s->polygon_area); free(s->tri_cum); free(s->tri_poly); free(s->poly_box);
-	free(s->nodes); free(s->mats); free(s->lights);
+	free(s->nodes); free(s->mats); free(s->lights); free(s->env);
 	free(s);
 }
 uint64_t orc_scene_n_polygons(const orc_scene *s) { return s->n_polys; }
@@ -921,6 +925,21 @@ uint64_t orc_trace_bvh2(const orc_scene *s, const void *nodes_v, uint64_t n_node
 /* ======================================================================================= */
 /* Materials (materialnode.cpp) and Renderer::LoadMaterials (renderer.cpp:24-44)            */
 /* ======================================================================================= */
+/* stands for stbi_load into the globals env_mapping_texture/width/height/bpp and env_brightness (scene.cpp:245, scene.h:20-22);
+ * tex == NULL removes the environment */
+int orc_scene_set_environment(orc_scene *s, const uint8_t *tex, int w, int h, int bpp, double brightness)
+{
+	free(s->env);
+	s->env = NULL;
+	if (tex == NULL) return 0;
+	if (w <= 0 || h <= 0 || bpp < 3) return -1;
+	s->env = (uint8_t *)malloc((size_t)w * h * bpp);
+	if (!s->env) return -1;
+	memcpy(s->env, tex, (size_t)w * h * bpp);
+	s->env_w = w; s->env_h = h; s->env_bpp = bpp; s->env_brightness = brightness;
+	return 0;
+}
+
 int orc_scene_set_materials(orc_scene *s, const orc_material *per_object, uint32_t n_objects)
 {
 	if (n_objects != s->n_objects) return 0;
@@ -1071,6 +1090,46 @@ static void random_point_on_polygon(const orc_scene *s, uint64_t f, uint64_t *rn
 	*normal = s->face_normal[f];
 }
 
+/* Sphere::Hit (object.cpp:43-75) for the dome of renderer.cpp:169-171: centre 0, radius 100.  Returns t only. */
+int orc_sphere_hit(const double o[3], const double d[3], double t_min, double t_max, double *t)
+{
+	const double radius = 100.0;
+	double blen = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+	double a = pow(blen, 2.0);
+	double b_prime = o[0] * d[0] + o[1] * d[1] + o[2] * d[2];
+	double c = pow(sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]), 2.0) - pow(radius, 2.0);
+	double disc = pow(b_prime, 2.0) - a * c;
+	if (disc < 0.0) return 0;
+	double t1 = (-b_prime - sqrt(disc)) / a;
+	if (t1 >= t_min && t1 <= t_max) { *t = t1; return 1; }
+	double t2 = (-b_prime + sqrt(disc)) / a;
+	if (t2 >= t_min && t2 <= t_max) { *t = t2; return 1; }
+	return 0;
+}
+
+/* renderer.cpp:180-191: direction of the dome point -> texel -> RGBtoSpectrum(rgb * brightness).get(central_wl).
+ * The reference's x can equal the width (it then reads the first texel of the next row) and, on the last row or for
+ * theta = pi, an address past the texture (undefined there); here such an address reads the last texel. */
+double orc_environment_lookup(const uint8_t *tex, int w, int h, int bpp, double brightness, const double o[3], const double d[3],
+                              double t, double central_wl)
+{
+	double p[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+	double l = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+	p[0] /= l; p[1] /= l; p[2] /= l;
+	double theta = acos(p[1]);
+	double phi = atan2(p[0] / sin(theta), p[2] / sin(theta));
+	phi += M_PI;
+	int x = w - (int)(phi / (2.0 * M_PI) * w);
+	int y = (int)(theta / M_PI * h);
+	long idx = (long)x + (long)y * w;
+	if (idx < 0) idx = 0;
+	if (idx > (long)w * h - 1) idx = (long)w * h - 1;
+	double rgb[3], spec[ORC_NBINS];
+	for (int c = 0; c < 3; c++) rgb[c] = (double)tex[(long)bpp * idx + c] / 255.0 * brightness;
+	orc_rgb_to_spectrum(rgb, spec);
+	return orc_spectrum_get(spec, central_wl);
+}
+
 static double geometry_term(const hitrec *rec0, const hitrec *rec1) /* renderer.cpp:784-789 */
 {
 	v3 v = vsub(rec1->p, rec0->p);
@@ -1088,8 +1147,14 @@ static double naive_path_tracing(const orc_scene *s, v3 o, v3 d, const band *b, 
 	double radiance = 0.0, beta = 1.0;
 	for (;;) {
 		st->closest_rays++;
-		if (!world_hit(s, WORLD_MODE, o, d, 0.001, DBL_MAX, &rec))
-			break; /* no environment texture loaded: :176-177 */
+		if (!world_hit(s, WORLD_MODE, o, d, 0.001, DBL_MAX, &rec)) {
+			if (s->env == NULL) /* :176-177 */
+				break;
+			double t;
+			if (orc_sphere_hit(o.e, d.e, 0.001, DBL_MAX, &t)) /* :178 */
+				radiance += beta * orc_environment_lookup(s->env, s->env_w, s->env_h, s->env_bpp, s->env_brightness, o.e, d.e, t, b->central_wl);
+			break;
+		}
 		const orc_material *m = rec_mat(s, &rec);
 		radiance += beta * mat_emitted(m, b);
 		onb uvw = onb_from_w(rec.normal);

@@ -131,6 +131,11 @@ typedef struct orc_material {
 } orc_material;
 /* returns 0 when no light polygons exist (renderer.cpp:41-42) */
 int orc_scene_set_materials(orc_scene *s, const orc_material *per_object, uint32_t n_objects); /* renderer.cpp:24-44 */
+/* environment texture of NaivePathTracing (renderer.cpp:175-193; globals of scene.h:20-22); parity unpinned */
+int orc_scene_set_environment(orc_scene *s, const uint8_t *tex, int w, int h, int bpp, double brightness);
+int orc_sphere_hit(const double o[3], const double d[3], double t_min, double t_max, double *t); /* object.cpp:43-75, dome of renderer.cpp:169-171 */
+double orc_environment_lookup(const uint8_t *tex, int w, int h, int bpp, double brightness, const double o[3], const double d[3],
+                              double t, double central_wl); /* renderer.cpp:180-191 */
 uint64_t orc_scene_n_lights(const orc_scene *s);
 
 enum { ORC_ALG_NAIVE = 0, ORC_ALG_NEE = 1, ORC_ALG_MIS = 2 }; /* renderer.h:12-18 */

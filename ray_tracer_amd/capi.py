@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libm
 
 # every symbol include/mi355rt.h declares
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_upload_materials", "rt_set_camera", "rt_clear",
+    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_environment", "rt_upload_materials", "rt_set_camera", "rt_clear",
     "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
     "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
     "rt_get_stats", "rt_get_bvh2", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
@@ -89,6 +89,7 @@ def load():
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_upload_mesh.argtypes = [vp, C.POINTER(Mesh)]
     lib.rt_set_builder.argtypes = [vp, C.c_int]
+    lib.rt_set_environment.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
     lib.rt_upload_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32]
     lib.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
     lib.rt_clear.argtypes = [vp]
@@ -158,6 +159,14 @@ class Context:
     def set_builder(self, builder):
         """BUILDER_HOST_SAH (default) or BUILDER_DEVICE_LBVH for the next upload_mesh"""
         self._check(self.lib.rt_set_builder(self.h, int(builder)))
+
+    def set_environment(self, texels, brightness=0.5):
+        """texels: uint8 [height, width, 3 or 4] (None removes the environment); brightness: env_brightness (scene.cpp:32)"""
+        if texels is None:
+            self._check(self.lib.rt_set_environment(self.h, None, 0, 0, 0, 0.0))
+            return
+        t = np.ascontiguousarray(texels, dtype=np.uint8)
+        self._check(self.lib.rt_set_environment(self.h, _ptr(t), t.shape[1], t.shape[0], t.shape[2], float(brightness)))
 
     def upload_materials(self, materials):
         """materials: list of dicts {type, light_flag, a, b}, one per obj object."""

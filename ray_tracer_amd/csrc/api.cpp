@@ -237,6 +237,16 @@ int rt_upload_materials(rt_context *ctx, const rt_material *per_object, uint32_t
 	return RT_OK;
 }
 
+int rt_set_environment(rt_context *ctx, const uint8_t *texels, int width, int height, int bpp, double brightness)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	if (texels && (width <= 0 || height <= 0 || bpp < 3 || bpp > 4)) return set_err(ctx, RT_ERR_INVALID, "rt_set_environment: needs width, height > 0 and 3 or 4 bytes per texel");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	std::string err;
+	if (render_set_environment(ctx->render, texels, width, height, bpp, brightness, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
+	return RT_OK;
+}
+
 int rt_set_camera(rt_context *ctx, const rt_camera *cam)
 {
 	if (!ctx || !cam) return set_err(ctx, RT_ERR_INVALID, "rt_set_camera: NULL argument");

@@ -9,6 +9,7 @@
 // being summed per path and added at the end; a NaN term is dropped on its own where the reference
 // drops the whole sample (renderer.cpp:115).
 #include <hip/hip_runtime.h>
+#include <cfloat>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -51,6 +52,9 @@ struct DeviceShade {
 	const uint32_t *light_faces;
 	const DevBand *bands;
 	uint32_t n_lights, n_bands;
+	const uint8_t *env;             // environment texture of the naive integrator (null: none), env_h rows of env_w texels
+	int env_w, env_h, env_bpp;
+	float env_brightness;
 };
 
 // 32 bytes per live path
@@ -87,6 +91,9 @@ struct Impl {
 	uint32_t *light_faces = nullptr;
 	DevBand *bands = nullptr;
 	uint32_t n_lights = 0, n_bands = 0;
+	uint8_t *env = nullptr;
+	int env_w = 0, env_h = 0, env_bpp = 0;
+	float env_brightness = 0.0f;
 	const uint32_t *tri_face = nullptr, *face_object = nullptr;
 	DevCamera cam{};
 	// queues
@@ -389,6 +396,38 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBan
 	state[idx] = st;
 }
 
+// Radiance of the environment for a ray that left the scene (renderer.cpp:175-191): Sphere::Hit on the dome of radius
+// 100 around the origin (object.cpp:43-75), direction of the dome point -> texel -> RGBtoSpectrum(rgb * brightness)
+// read at the band's bin (bins 0-9 blue, 10-19 green, 20-29 red, spectrum.cpp:219-232).  In fp64: it runs once per
+// escaping path and the texel index is a truncation, which fp32 would move across texel borders.
+// The reference's x can equal the width (it then reads the first texel of the next row) and, on the last row or for
+// theta = pi, an address past the texture (undefined there); here such an address reads the last texel.
+__device__ float environment_radiance(const DeviceShade &sh, const rt_ray &r, int get_bin)
+{
+	const double ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
+	const double blen = sqrt(dx * dx + dy * dy + dz * dz), olen = sqrt(ox * ox + oy * oy + oz * oz);
+	const double a = blen * blen, b_prime = ox * dx + oy * dy + oz * dz, c = olen * olen - 100.0 * 100.0;
+	const double disc = b_prime * b_prime - a * c;
+	if (disc < 0.0) return 0.0f;
+	double t = (-b_prime - sqrt(disc)) / a;
+	if (!(t >= 0.001 && t <= DBL_MAX)) {
+		t = (-b_prime + sqrt(disc)) / a;
+		if (!(t >= 0.001 && t <= DBL_MAX)) return 0.0f;
+	}
+	double px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+	const double l = sqrt(px * px + py * py + pz * pz);
+	px /= l; py /= l; pz /= l;
+	const double theta = acos(py);
+	const double phi = atan2(px / sin(theta), pz / sin(theta)) + 3.14159265358979323846;
+	const int x = sh.env_w - (int)(phi / (2.0 * 3.14159265358979323846) * sh.env_w);
+	const int y = (int)(theta / 3.14159265358979323846 * sh.env_h);
+	long idx = (long)x + (long)y * sh.env_w;
+	idx = idx < 0 ? 0 : idx;
+	idx = idx > (long)sh.env_w * sh.env_h - 1 ? (long)sh.env_w * sh.env_h - 1 : idx;
+	const int channel = get_bin < RT_NBINS / 3 ? 2 : (get_bin < 2 * RT_NBINS / 3 ? 1 : 0);
+	return (float)((double)sh.env[(long)sh.env_bpp * idx + channel] / 255.0 * (double)sh.env_brightness);
+}
+
 // ---------------------------------------------------------------------------------------------
 // shade: one path vertex.  Emission, light pick and light point, BSDF samples, Russian roulette in
 // the reference's order; appends connection rays and the continuation ray.
@@ -409,6 +448,10 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DeviceShade sh, const uin
 	if (live) {
 		st = state[idx];
 		const rt_hit h = hits[idx];
+		if (ALG == RT_ALG_NAIVE && h.prim == RT_MISS && sh.env != nullptr) { // renderer.cpp:175-193
+			const DevBand bd = sh.bands[st.band_bounce & 0xFFFFu];
+			film_add(film, st.pixel, bd, st.beta * environment_radiance(sh, rays[idx], bd.get_bin) * st.weight);
+		}
 		if (h.prim != RT_MISS) {
 			const rt_ray r = rays[idx];
 			const uint32_t band = st.band_bounce & 0xFFFFu, bounce = st.band_bounce >> 16;
@@ -677,6 +720,11 @@ DeviceShade make_shade(const Impl &im)
 	sh.bands = im.bands;
 	sh.n_lights = im.n_lights;
 	sh.n_bands = im.n_bands;
+	sh.env = im.env;
+	sh.env_w = im.env_w;
+	sh.env_h = im.env_h;
+	sh.env_bpp = im.env_bpp;
+	sh.env_brightness = im.env_brightness;
 	return sh;
 }
 
@@ -995,6 +1043,22 @@ hipError_t render_download_preview(RenderState &rs, int samples_done, double *ou
 	return e;
 }
 
+hipError_t render_set_environment(RenderState &rs, const uint8_t *texels, int width, int height, int bpp, double brightness, hipStream_t stream, std::string &err)
+{
+	Impl &im = *impl_of(rs);
+	HIP_TRY(hipStreamSynchronize(stream)); // no render may still be reading the old texture
+	if (im.env) { (void)hipFree(im.env); im.env = nullptr; }
+	if (!texels) return hipSuccess;
+	const size_t bytes = (size_t)width * height * bpp;
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&im.env), bytes));
+	HIP_TRY(hipMemcpy(im.env, texels, bytes, hipMemcpyHostToDevice));
+	im.env_w = width;
+	im.env_h = height;
+	im.env_bpp = bpp;
+	im.env_brightness = (float)brightness;
+	return hipSuccess;
+}
+
 void render_free(RenderState &rs)
 {
 	if (rs.impl) {
@@ -1008,6 +1072,7 @@ void render_free(RenderState &rs)
 		if (im.materials) (void)hipFree(im.materials);
 		if (im.light_faces) (void)hipFree(im.light_faces);
 		if (im.bands) (void)hipFree(im.bands);
+		if (im.env) (void)hipFree(im.env);
 		if (im.counters) {
 			(void)hipFree(im.counters);
 			for (auto &e : im.ev) if (e) (void)hipEventDestroy(e);

@@ -79,6 +79,15 @@ bool Renderer::LoadMaterials(const std::map<std::string, std::shared_ptr<NodeMat
 	return rc == RT_OK; // RT_ERR_NO_LIGHTS: `light_objects.size() == 0` in the reference
 }
 
+bool Renderer::SetEnvironment(const uint8_t *texels, int width, int height, int bpp, double brightness)
+{
+	if (!gpu || rt_set_environment(gpu, texels, width, height, bpp, brightness) != RT_OK) {
+		last_error = gpu ? rt_last_error(gpu) : "no device";
+		return false;
+	}
+	return true;
+}
+
 void Renderer::Clear(void) // renderer.cpp:47-51
 {
 	obj_loader.Clear();

@@ -29,6 +29,9 @@ public:
 	bool LoadPly(const char *plyfilename, const char *object_name, PlyNormals normals = PlyNormals::Auto);
 	bool LoadMaterials(const std::map<std::string, std::shared_ptr<NodeMaterial>> &materials);
 	void Clear(void);
+	// the reference keeps these in globals (env_mapping_texture, env_mapping_width, env_mapping_height, env_mapping_bpp,
+	// env_brightness: scene.h:20-22) that NaivePathTracing reads (renderer.cpp:175-193); texels == nullptr: no environment
+	bool SetEnvironment(const uint8_t *texels, int width, int height, int bpp, double brightness);
 	void RenderImage(int nx, int ny, int ns, int spectral_samples, bool enable_openmp, bool print_progress = false);
 	enum RenderingAlgorithm algorithm_type = NaiveBDPTType; // renderer.h:33
 	std::vector<Spectrum> spectrum_img;

@@ -45,6 +45,11 @@ class Renderer:
         self.ctx.upload_mesh(self.mesh)
         return True
 
+    def SetEnvironment(self, texels, brightness=0.5):
+        """The reference keeps the environment in globals that NaivePathTracing reads (env_mapping_texture, width, height,
+        bpp, env_brightness: scene.h:20-22, renderer.cpp:175-193).  texels: uint8 [height, width, 3 or 4], None = none."""
+        self.ctx.set_environment(texels, brightness)
+
     def LoadMesh(self, mesh):
         """Same as Load for a mesh already in memory (synthetic scenes)."""
         self.obj_loader = Obj()

@@ -187,6 +187,14 @@ class Scene:
                 arr[i].b[k] = float(m["b"][k])
         return lib().orc_scene_set_materials(self.h, arr, len(records))
 
+    def set_environment(self, texels, brightness=0.5):
+        L = lib()
+        L.orc_scene_set_environment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
+        if texels is None:
+            return L.orc_scene_set_environment(self.h, None, 0, 0, 0, 0.0)
+        t = np.ascontiguousarray(texels, dtype=np.uint8)
+        return L.orc_scene_set_environment(self.h, _p(t), t.shape[1], t.shape[0], t.shape[2], float(brightness))
+
     def render(self, cam, nx, ny, ns, spectral_samples, algorithm, seed, first_sample=0, n_samples=None, nthreads=0):
         self.build_bvh()
         film = np.zeros((nx * ny, NBINS), dtype=np.float64)

@@ -145,3 +145,41 @@ def test_cpp_host_renderer_matches_the_python_host(ctx, cornell_dir, tmp_path):
     assert got.shape == want.shape
     assert np.allclose(got, want, rtol=1e-5, atol=1e-9)  # same kernels, same inputs; fp32 atomics may reorder sums
     assert (tmp_path / "img.ppm").read_text().startswith("P3\n40 30\n255\n")
+
+
+def test_environment_texture_naive(ctx, cornell_dir):
+    """NaivePathTracing's environment lookup on a miss (renderer.cpp:175-193) against the oracle's restatement, same random
+    streams: a texture with distinct texels everywhere so that a wrong texel or channel shows"""
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 40, 30)
+    rng = np.random.default_rng(9)
+    tex = rng.integers(0, 256, (16, 32, 4), dtype=np.uint8)
+    sc = oracle.Scene(mesh)
+    sc.set_materials(records)
+    sc.set_environment(tex, 0.8)
+    want, _ = sc.render(oc, 40, 30, 8, 30, oracle.ALG_NAIVE, seed=11)
+    ctx.upload_mesh(mesh)
+    ctx.upload_materials(records)
+    ctx.set_camera(cam)
+    ctx.set_environment(tex, 0.8)
+    films = {}
+    for alg in (capi.ALG_NAIVE, capi.ALG_MIS):
+        ctx.render_begin(40, 30, 8, 30, alg, 11)
+        ctx.render_pass(0, 8)
+        ctx.render_sync()
+        films[alg] = ctx.download_film()
+    ctx.set_environment(None)
+    ctx.render_begin(40, 30, 8, 30, capi.ALG_NAIVE, 11)
+    ctx.render_pass(0, 8)
+    ctx.render_sync()
+    dark = ctx.download_film()
+    ctx.render_begin(40, 30, 8, 30, capi.ALG_MIS, 11)
+    ctx.render_pass(0, 8)
+    ctx.render_sync()
+    mis_dark = ctx.download_film()
+    got = films[capi.ALG_NAIVE]
+    assert got.sum() > 1.2 * dark.sum()  # the environment adds light through the open side
+    assert abs(got.sum() - want.sum()) <= 1e-3 * want.sum()
+    close = np.isclose(got, want, rtol=1e-3, atol=1e-7)
+    assert close.mean() > 0.99
+    assert np.sqrt(((got - want) ** 2).mean()) <= 0.05 * np.sqrt((want ** 2).mean())
+    assert np.allclose(films[capi.ALG_MIS], mis_dark, rtol=1e-5, atol=1e-9)  # only the naive integrator reads it

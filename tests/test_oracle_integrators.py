@@ -6,6 +6,7 @@ renderer cannot be built here and its tests hold no vectors.  What these check:
   * the three integrators estimate nearly the same image;
   * closed-form unit checks of the pieces (Fresnel, power heuristic, cosine sampler quirk).
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -79,3 +80,46 @@ def test_emission_band_integral():
     assert abs(L.orc_spectrum_integrate(oracle._p(s), 400.0, 409.99999) - 19.99999) < 1e-9
     assert abs(L.orc_spectrum_integrate(oracle._p(s), 690.0, 699.99999) - 10.0) < 1e-9
     assert abs(L.orc_spectrum_integrate(oracle._p(s), 400.0, 699.999) - 300.0) < 1e-9
+
+
+def test_environment_lookup_restated():
+    """renderer.cpp:175-191 + Sphere::Hit (object.cpp:43-75); parity unpinned (renderer.cpp and object.cpp do not compile here),
+    so this checks the restatement against the formulas worked by hand"""
+    L = oracle.lib()
+    L.orc_sphere_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    L.orc_environment_lookup.restype = C.c_double
+    L.orc_environment_lookup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+    o, d = np.array([0.0, 0.0, 3.0]), np.array([0.0, 0.0, 2.0])
+    t = C.c_double()
+    assert L.orc_sphere_hit(oracle._p(o), oracle._p(d), 0.001, 1e308, C.byref(t)) == 1
+    assert abs(t.value - (100.0 - 3.0) / 2.0) < 1e-12  # the far root: the near one is behind the origin
+    far = np.array([0.0, 0.0, 300.0])
+    assert L.orc_sphere_hit(oracle._p(far), oracle._p(d), 0.001, 1e308, C.byref(t)) == 0
+    w, h = 8, 4
+    tex = np.arange(w * h * 3, dtype=np.uint8).reshape(h, w, 3)
+    for direction, band_wl in (((0.3, 0.5, -0.8), 455.0), ((-0.7, -0.2, 0.1), 555.0), ((0.0, 0.99, 0.1), 655.0)):
+        dd = np.array(direction)
+        origin = np.zeros(3)
+        assert L.orc_sphere_hit(oracle._p(origin), oracle._p(dd), 0.001, 1e308, C.byref(t)) == 1
+        got = L.orc_environment_lookup(oracle._p(tex), w, h, 3, 0.5, oracle._p(origin), oracle._p(dd), t.value, band_wl)
+        p = dd / np.linalg.norm(dd)
+        theta = np.arccos(p[1])
+        phi = np.arctan2(p[0] / np.sin(theta), p[2] / np.sin(theta)) + np.pi
+        x, y = w - int(phi / (2 * np.pi) * w), int(theta / np.pi * h)
+        idx = min(max(x + y * w, 0), w * h - 1)
+        channel = {455.0: 2, 555.0: 1, 655.0: 0}[band_wl]  # RGBtoSpectrum: bins 0-9 blue, 10-19 green, 20-29 red
+        assert got == tex.reshape(-1, 3)[idx, channel] / 255.0 * 0.5
+
+
+def test_environment_lights_the_open_side_of_the_box(cornell_dir):
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 24, 24)
+    sc = oracle.Scene(mesh)
+    sc.set_materials(records)
+    dark, _ = sc.render(oc, 24, 24, 16, 30, oracle.ALG_NAIVE, seed=3)
+    sc.set_environment(np.full((4, 8, 3), 255, dtype=np.uint8), 2.0)
+    lit, _ = sc.render(oc, 24, 24, 16, 30, oracle.ALG_NAIVE, seed=3)
+    assert lit.sum() > 1.5 * dark.sum()
+    nee, _ = sc.render(oc, 24, 24, 4, 30, oracle.ALG_NEE, seed=3)
+    sc.set_environment(None)
+    nee0, _ = sc.render(oc, 24, 24, 4, 30, oracle.ALG_NEE, seed=3)
+    assert np.array_equal(nee, nee0)  # only the naive integrator reads it (renderer.cpp:175)
