@@ -208,6 +208,11 @@ int rt_get_stats(rt_context *ctx, rt_stats *out);
 /* copies the host-built BVH2: nodes (n_nodes records) and tri_index (leaf order -> fan triangle).
  * Pass NULL pointers to query the counts only. */
 int rt_get_bvh2(rt_context *ctx, rt_bvh2_node *nodes, uint64_t *n_nodes, uint32_t *tri_index, uint64_t *n_tris);
+/* replaces: BiliteralFilter::FilterImage (filter.cpp:13-51; window / sigma_d / sigma_r are the public fields of filter.h:17-27).
+ * rgba, out: width * height * 4 doubles, row major, as Filter::orig_img / Filter::result.  Host buffers. */
+int rt_filter_bilateral(rt_context *ctx, const double *rgba, int width, int height, int window, double sigma_d, double sigma_r, double *out);
+/* the same on buffers already in HBM (they may not alias); runs on the context's stream, rt_render_sync waits for it */
+int rt_filter_bilateral_device(rt_context *ctx, const void *d_rgba, int width, int height, int window, double sigma_d, double sigma_r, void *d_out);
 /* the context's stream as a hipStream_t, for callers that time with HIP events */
 void *rt_stream(rt_context *ctx);
 

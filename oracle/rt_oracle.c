@@ -46,6 +46,38 @@ int orc_num_threads(void)
 #endif
 }
 
+/* BiliteralFilter::FilterImage (filter.cpp:13-51), statement for statement.  img, result: width*height*4 doubles. */
+void orc_bilateral(const double *img, int img_width, int img_height, int window, double sigma_d, double sigma_r, double *result)
+{
+	for (int x = 0; x < img_width; x++) {
+		for (int y = 0; y < img_height; y++) {
+			double sum[3] = {0.0, 0.0, 0.0};
+			double W[3] = {0.0, 0.0, 0.0};
+			for (int i = -window; i <= window; i++) {
+				for (int j = -window; j <= window; j++) {
+					for (int c = 0; c < 3; c++) {
+						int wx = x + i;
+						int wy = y + j;
+						if (wx < 0) wx = 0;
+						if (wx >= img_width) wx = img_width - 1;
+						if (wy < 0) wy = 0;
+						if (wy >= img_height) wy = img_height - 1;
+						double orig_value = img[((img_height - y - 1) * img_width + x) * 4 + c];
+						double orig_wvalue = img[((img_height - wy - 1) * img_width + wx) * 4 + c];
+						double power_index = -(double)((wx - x) * (wx - x) + (wy - y) * (wy - y)) / (2.0 * sigma_d * sigma_d);
+						power_index += -(pow(orig_value - orig_wvalue, 2.0) / (2.0 * sigma_r * sigma_r));
+						double w = exp(power_index);
+						sum[c] += orig_wvalue * w;
+						W[c] += w;
+					}
+				}
+			}
+			for (int c = 0; c < 3; c++) result[((img_height - y - 1) * img_width + x) * 4 + c] = sum[c] / W[c];
+			result[((img_height - y - 1) * img_width + x) * 4 + 3] = 1.0;
+		}
+	}
+}
+
 /* ======================================================================================= */
 /* AABB (aabb.cpp)                                                                          */
 /* ======================================================================================= */

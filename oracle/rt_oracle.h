@@ -130,6 +130,8 @@ typedef struct orc_material {
 	double b[ORC_NBINS];                /* k | surface_color */
 } orc_material;
 /* returns 0 when no light polygons exist (renderer.cpp:41-42) */
+/* BiliteralFilter::FilterImage (filter.cpp:13-51); pinned by the compiled reference (oracle/_ref/libref_filter.so) */
+void orc_bilateral(const double *img, int img_width, int img_height, int window, double sigma_d, double sigma_r, double *result);
 int orc_scene_set_materials(orc_scene *s, const orc_material *per_object, uint32_t n_objects); /* renderer.cpp:24-44 */
 /* environment texture of NaivePathTracing (renderer.cpp:175-193; globals of scene.h:20-22); parity unpinned */
 int orc_scene_set_environment(orc_scene *s, const uint8_t *tex, int w, int h, int bpp, double brightness);

@@ -18,7 +18,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_environment", "rt_upload_materials", "rt_set_camera", "rt_clear",
     "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
     "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
-    "rt_get_stats", "rt_get_bvh2", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
+    "rt_get_stats", "rt_get_bvh2", "rt_filter_bilateral", "rt_filter_bilateral_device", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
 ]
 
 RAY_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("oz", "f4"), ("tmin", "f4"),
@@ -89,6 +89,8 @@ def load():
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_upload_mesh.argtypes = [vp, C.POINTER(Mesh)]
     lib.rt_set_builder.argtypes = [vp, C.c_int]
+    lib.rt_filter_bilateral.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]
+    lib.rt_filter_bilateral_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]
     lib.rt_set_environment.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
     lib.rt_upload_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32]
     lib.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
@@ -167,6 +169,16 @@ class Context:
             return
         t = np.ascontiguousarray(texels, dtype=np.uint8)
         self._check(self.lib.rt_set_environment(self.h, _ptr(t), t.shape[1], t.shape[0], t.shape[2], float(brightness)))
+
+    def filter_bilateral(self, rgba, window, sigma_d, sigma_r):
+        """rgba: float64 [height, width, 4]; returns the filtered image (BiliteralFilter::FilterImage, filter.cpp:13-51)"""
+        img = np.ascontiguousarray(rgba, dtype=np.float64)
+        out = np.empty_like(img)
+        self._check(self.lib.rt_filter_bilateral(self.h, _ptr(img), img.shape[1], img.shape[0], int(window), float(sigma_d), float(sigma_r), _ptr(out)))
+        return out
+
+    def filter_bilateral_device(self, d_rgba, width, height, window, sigma_d, sigma_r, d_out):
+        self._check(self.lib.rt_filter_bilateral_device(self.h, d_rgba, width, height, int(window), float(sigma_d), float(sigma_r), d_out))
 
     def upload_materials(self, materials):
         """materials: list of dicts {type, light_flag, a, b}, one per obj object."""

@@ -7,6 +7,7 @@
 #include <vector>
 #include "context.h"
 #include "device_build.h"
+#include "filter.h"
 #include "trace.h"
 
 using namespace mi355rt;
@@ -418,6 +419,36 @@ int rt_get_bvh2(rt_context *ctx, rt_bvh2_node *nodes, uint64_t *n_nodes, uint32_
 	if (nodes) std::memcpy(nodes, ctx->bvh.nodes.data(), ctx->bvh.nodes.size() * sizeof(rt_bvh2_node));
 	if (tri_index) std::memcpy(tri_index, ctx->bvh.tri_index.data(), ctx->bvh.tri_index.size() * sizeof(uint32_t));
 	return RT_OK;
+}
+
+int rt_filter_bilateral_device(rt_context *ctx, const void *d_rgba, int width, int height, int window, double sigma_d, double sigma_r, void *d_out)
+{
+	if (!ctx || !d_rgba || !d_out) return set_err(ctx, RT_ERR_INVALID, "rt_filter_bilateral: NULL argument");
+	if (width <= 0 || height <= 0 || window < 0 || window > 64) return set_err(ctx, RT_ERR_INVALID, "rt_filter_bilateral: needs width, height > 0 and 0 <= window <= 64");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	hipError_t e = launch_bilateral((const double *)d_rgba, width, height, window, sigma_d, sigma_r, (double *)d_out, ctx->stream);
+	if (ctx->fail_hip(e, "k_bilateral")) return RT_ERR_HIP;
+	return RT_OK;
+}
+
+int rt_filter_bilateral(rt_context *ctx, const double *rgba, int width, int height, int window, double sigma_d, double sigma_r, double *out)
+{
+	if (!ctx || !rgba || !out) return set_err(ctx, RT_ERR_INVALID, "rt_filter_bilateral: NULL argument");
+	if (width <= 0 || height <= 0) return set_err(ctx, RT_ERR_INVALID, "rt_filter_bilateral: needs width, height > 0");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	const size_t bytes = (size_t)width * height * 4 * sizeof(double);
+	void *d_in = nullptr, *d_out = nullptr;
+	int rc = RT_OK;
+	if (ctx->fail_hip(hipMalloc(&d_in, bytes), "hipMalloc") || ctx->fail_hip(hipMalloc(&d_out, bytes), "hipMalloc") ||
+	    ctx->fail_hip(hipMemcpy(d_in, rgba, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D"))
+		rc = RT_ERR_HIP;
+	if (rc == RT_OK) rc = rt_filter_bilateral_device(ctx, d_in, width, height, window, sigma_d, sigma_r, d_out);
+	if (rc == RT_OK && (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize") ||
+	                    ctx->fail_hip(hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H")))
+		rc = RT_ERR_HIP;
+	if (d_in) (void)hipFree(d_in);
+	if (d_out) (void)hipFree(d_out);
+	return rc;
 }
 
 void *rt_stream(rt_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }

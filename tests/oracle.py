@@ -310,3 +310,24 @@ def ply_oracle():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def ref_filter():
+    """the reference's own filter.cpp, compiled unmodified (present only where the reference checkout is)"""
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_filter.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.ref_bilateral.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+    return L
+
+
+def bilateral(img, window, sigma_d, sigma_r, fn=None):
+    """img: [height, width, 4] float64; fn: ref_filter().ref_bilateral, default the oracle's restatement"""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    out = np.zeros_like(img)
+    if fn is None:
+        fn = lib().orc_bilateral
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+    fn(_p(img), img.shape[1], img.shape[0], int(window), float(sigma_d), float(sigma_r), _p(out))
+    return out
