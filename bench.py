@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--soup-rays", type=int, default=1 << 24)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (roofline then lacks the work-unit counts)")
     ap.add_argument("--no-soup", action="store_true")
+    ap.add_argument("--algorithm", default="mis", choices=["naive", "nee", "mis", "bdpt"],
+                    help="integrator of the timed workload (the headline metric is quoted on mis)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -209,7 +211,8 @@ def main():
     ns_total = per_rank * world
     assert parallel.sample_range(rank, world, ns_total) == (rank * per_rank, per_rank)
     film = torch.zeros(nx * ny * capi.NBINS, dtype=torch.float32, device="cuda")
-    ctx.render_begin(nx, ny, ns_total, 30, capi.ALG_MIS, 20261111, film.data_ptr())
+    alg = {"naive": capi.ALG_NAIVE, "nee": capi.ALG_NEE, "mis": capi.ALG_MIS, "bdpt": capi.ALG_NAIVE_BDPT}[args.algorithm]
+    ctx.render_begin(nx, ny, ns_total, 30, alg, 20261111, film.data_ptr())
     first = rank * per_rank
     for s in range(args.warmup):
         ctx.render_pass(first + s * spp, spp)
@@ -263,8 +266,9 @@ def main():
             "value": args.steps * spp * world / dt, "unit": "spp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 triangle test, f32 box test and shading", "data": "synthetic",
-            "config": {"workload": "Cornell box (example/cornell_box_triangulated.obj + materials.json) %dx%d, NEE+MIS, 30 spectral bands, "
-                                   "%d spp per step, %d spp timed per GPU" % (nx, ny, spp, args.steps * spp),
+            "config": {"workload": "Cornell box (example/cornell_box_triangulated.obj + materials.json) %dx%d, %s, 30 spectral bands, "
+                                   "%d spp per step, %d spp timed per GPU" % (nx, ny, {"mis": "NEE+MIS", "nee": "NEE", "naive": "naive path tracing",
+                                                                                      "bdpt": "NaiveBDPT"}[args.algorithm], spp, args.steps * spp),
                        "parallelism": "samples sharded over %d GPU(s), one RCCL all-reduce of the film" % world},
             "msamples_per_s": args.steps * spp * world * nx * ny / dt / 1e6,
             "rays_per_sample": (stats["closest_rays"] + stats["any_rays"]) / max(stats["camera_samples"], 1),

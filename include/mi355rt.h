@@ -101,7 +101,9 @@ typedef struct rt_camera {
 typedef enum rt_algorithm { /* enum RenderingAlgorithm, renderer.h:12-18 */
 	RT_ALG_NAIVE = 0,  /* Renderer::NaivePathTracing, renderer.cpp:163-224 */
 	RT_ALG_NEE = 1,    /* Renderer::NEEPathTracingWithoutSpecular, renderer.cpp:227-325 */
-	RT_ALG_MIS = 2     /* Renderer::NEEMISPathTracing, renderer.cpp:329-475 */
+	RT_ALG_MIS = 2,    /* Renderer::NEEMISPathTracing, renderer.cpp:329-475 */
+	RT_ALG_NAIVE_BDPT = 3, /* Renderer::NaiveBDPT, renderer.cpp:478-771 (the default of renderer.h:33) */
+	RT_ALG_MIS_BDPT = 4    /* Renderer::MISBDPT, renderer.cpp:775-778: returns 0, the film stays empty */
 } rt_algorithm;
 
 typedef struct rt_stats {

@@ -1028,9 +1028,10 @@ static double mat_pdf(const orc_material *m, v3 vi, v3 vo)
 	}
 }
 
-/* ImportanceType rays only (every integrator call site passes ImportanceType) */
-static int mat_sample(const orc_material *m, v3 normal, const onb *uvw, v3 vo, double wlo, uint64_t *rng, v3 *vi,
-                      double *ratio, double *bsdf, double *pdfval)
+/* light_type: RayType of the call (material.h): 0 = ImportanceType (paths from the eye), 1 = LightType (the light subpath of
+ * NaiveBDPT, renderer.cpp:589); only the refraction branch of the dielectric tells them apart (materialnode.cpp:399-403) */
+static int mat_sample_t(const orc_material *m, v3 normal, const onb *uvw, v3 vo, double wlo, uint64_t *rng, v3 *vi,
+                        double *ratio, double *bsdf, double *pdfval, int light_type)
 {
 	switch (m->type) {
 	case ORC_MAT_LAMBERTIAN: { /* :262-276 with CosinePdf pdf.cpp:70-84 */
@@ -1067,7 +1068,7 @@ static int mat_sample(const orc_material *m, v3 normal, const onb *uvw, v3 vo, d
 			double sin_t = sin_o / rel;
 			double cos_t = sqrt(1.0 - sin_t * sin_t);
 			*vi = vsub(vscale(-cos_t, nrm), vscale(sin_t, vunit(V(vo.e[0], vo.e[1], 0))));
-			*ratio = surface_scale / pow(rel, 3) / cos_t;
+			*ratio = light_type ? surface_scale * pow(rel, 3) / cos_t : surface_scale / pow(rel, 3) / cos_t;
 		}
 		return 1;
 	}
@@ -1094,6 +1095,12 @@ static int mat_sample(const orc_material *m, v3 normal, const onb *uvw, v3 vo, d
 	default: /* DiffuseLight and unconnected outputs: base class, :203-206 */
 		return 0;
 	}
+}
+
+static int mat_sample(const orc_material *m, v3 normal, const onb *uvw, v3 vo, double wlo, uint64_t *rng, v3 *vi,
+                      double *ratio, double *bsdf, double *pdfval)
+{
+	return mat_sample_t(m, normal, uvw, vo, wlo, rng, vi, ratio, bsdf, pdfval, 0);
 }
 
 /* ConvexPolygon::GetRandomPointOnPolygon (object.cpp:340-372) */
@@ -1347,11 +1354,174 @@ static double mis_path_tracing(const orc_scene *s, v3 o, v3 d, const band *b, ui
 	return radiance;
 }
 
+/* NaiveBDPT (renderer.cpp:478-771), statement order kept.  Subpaths are std::vectors in the reference; here they are capped at
+ * ORC_BDPT_MAX vertices each (survival beyond vertex k has probability 0.25 * 0.1^(k-2): 2.5e-7 at 8), the same cap the device uses. */
+#define ORC_BDPT_MAX 8
+static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t *rng, orc_render_stats *st)
+{
+	const v3 cam_o = o, cam_d = d;
+	/* ---- eye subpath, :482-529 */
+	hitrec erec[ORC_BDPT_MAX];
+	v3 eray_d[ORC_BDPT_MAX];
+	double alphas[ORC_BDPT_MAX];
+	size_t K = 0;
+	double alpha = 1.0, alpha_ = 1.0;
+	int last_eye_ray_hit = 0; /* what world->Hit(_ray, ...) at :558 returns: _ray is still the eye subpath's last ray there */
+	for (;;) {
+		hitrec rec;
+		st->closest_rays++;
+		last_eye_ray_hit = world_hit(s, WORLD_MODE, o, d, 0.001, DBL_MAX, &rec);
+		if (!last_eye_ray_hit) break;
+		const orc_material *m = rec_mat(s, &rec);
+		if (m->light_flag) break;
+		alpha *= alpha_;
+		onb uvw = onb_from_w(rec.normal);
+		v3 gvi;
+		double ratio, bsdf, pdf;
+		if (!mat_sample(m, rec.normal, &uvw, onb_w2l(&uvw, vneg(d)), b->central_wl, rng, &gvi, &ratio, &bsdf, &pdf)) break;
+		alpha_ = ratio * fabs(gvi.e[2]);
+		if (K == ORC_BDPT_MAX) break; /* cap (not in the reference) */
+		alphas[K] = alpha; erec[K] = rec; eray_d[K] = d;
+		double prr = 0.5;
+		K++;
+		if (K > 2) prr = 0.9;
+		if (orc_rng_f64(rng) < prr) break;
+		alpha_ /= (1.0 - prr);
+		o = rec.p;
+		d = vunit(onb_l2w(&uvw, gvi));
+	}
+	/* ---- light subpath, :538-613 */
+	uint64_t sel = rng_below(rng, (uint32_t)s->n_lights);
+	uint64_t lf = s->lights[sel];
+	v3 pol, light_normal;
+	double light_area;
+	random_point_on_polygon(s, lf, rng, &pol, &light_area, &light_normal);
+	double light_pdf_area = 1.0 / light_area / (double)s->n_lights;
+	onb lb = onb_from_w(light_normal); /* CosinePdf pdf(light_normal), pdf.cpp:70-84 */
+	double c3[3];
+	{
+		double r1 = orc_rng_f64(rng), r2 = orc_rng_f64(rng);
+		orc_cosine_hemisphere(r1, r2, c3);
+	}
+	v3 dir = onb_l2w(&lb, V(c3[0], c3[1], c3[2]));
+	double cos_l = vdot(dir, lb.axis[2]);
+	double light_dir_pdf_solidangle = cos_l >= 0.0 ? cos_l / M_PI : 0.0;
+	double light_dir_pdf_projected = light_dir_pdf_solidangle / vdot(light_normal, dir);
+	double light_value = 0.0;
+	st->closest_rays++; /* :558 traces _ray (the eye subpath's last ray), not shadow_ray: same result as that ray's own trace */
+	if (last_eye_ray_hit) light_value = mat_emitted(&s->mats[s->object_id[lf]], b);
+	hitrec lrec[ORC_BDPT_MAX];
+	v3 lray_d[ORC_BDPT_MAX];
+	double betas[ORC_BDPT_MAX];
+	size_t L = 0;
+	double beta = 1.0, beta_ = 1.0;
+	o = pol;
+	d = dir;
+	for (;;) {
+		hitrec rec;
+		st->closest_rays++;
+		if (!world_hit(s, WORLD_MODE, o, d, 0.001, DBL_MAX, &rec)) break;
+		const orc_material *m = rec_mat(s, &rec);
+		if (m->light_flag) break;
+		beta *= beta_;
+		onb uvw = onb_from_w(rec.normal);
+		v3 gvi;
+		double ratio, bsdf, pdf;
+		if (!mat_sample_t(m, rec.normal, &uvw, onb_w2l(&uvw, vneg(d)), b->central_wl, rng, &gvi, &ratio, &bsdf, &pdf, 1)) break;
+		beta_ = ratio * fabs(gvi.e[2]);
+		if (L == ORC_BDPT_MAX) break; /* cap (not in the reference) */
+		betas[L] = beta; lrec[L] = rec; lray_d[L] = d;
+		double prr = 0.5;
+		L++;
+		if (L > 2) prr = 0.9;
+		if (orc_rng_f64(rng) < prr) break;
+		beta_ /= (1.0 - prr);
+		o = rec.p;
+		d = vunit(onb_l2w(&uvw, gvi));
+	}
+	/* ---- contributions by path length, :619-769 */
+	double radiances[2 * ORC_BDPT_MAX + 1];
+	size_t path_numbers[2 * ORC_BDPT_MAX + 1];
+	const size_t n_len = K + (L + 1);
+	for (size_t i = 0; i < n_len; i++) { radiances[i] = 0.0; path_numbers[i] = 0; }
+	{ /* s = 0, t = 0, :632-642 */
+		path_numbers[0]++;
+		hitrec rec;
+		st->closest_rays++;
+		if (world_hit(s, WORLD_MODE, cam_o, cam_d, 0.001, DBL_MAX, &rec)) {
+			const orc_material *m = rec_mat(s, &rec);
+			if (m->light_flag) radiances[0] += mat_emitted(m, b) / (0 + 0 + 1);
+		}
+	}
+	for (size_t e = 0; e < K; e++) { /* s >= 1, t = 0, :654-686 */
+		size_t total_length = e + 2;
+		path_numbers[total_length - 1]++;
+		onb uvw = onb_from_w(erec[e].normal);
+		v3 gvi;
+		double ratio, bsdf, pdf;
+		if (!mat_sample(rec_mat(s, &erec[e]), erec[e].normal, &uvw, onb_w2l(&uvw, vneg(eray_d[e])), b->central_wl, rng, &gvi, &ratio, &bsdf, &pdf))
+			continue;
+		hitrec light_rec;
+		st->closest_rays++;
+		if (!world_hit(s, WORLD_MODE, erec[e].p, onb_l2w(&uvw, gvi), 0.001, DBL_MAX, &light_rec)) continue;
+		const orc_material *lm = rec_mat(s, &light_rec);
+		if (!lm->light_flag) continue;
+		const double light = mat_emitted(lm, b);
+		radiances[total_length - 1] += alphas[e] * ratio * fabs(gvi.e[2]) * light;
+	}
+	for (size_t e = 0; e < K; e++) { /* s >= 1, t = 1, :692-716 */
+		size_t total_length = e + 2;
+		path_numbers[total_length - 1]++;
+		hitrec light_rec;
+		st->closest_rays++;
+		if (!world_hit(s, WORLD_MODE, erec[e].p, vunit(vsub(pol, erec[e].p)), 0.001, DBL_MAX, &light_rec)) continue;
+		if ((uint64_t)light_rec.poly != lf) continue;
+		onb uvw = onb_from_w(erec[e].normal);
+		v3 vi = onb_w2l(&uvw, vunit(vsub(pol, erec[e].p)));
+		v3 vo = onb_w2l(&uvw, vneg(eray_d[e]));
+		double bsdf = mat_bsdf(rec_mat(s, &erec[e]), vi, b->central_wl, vo);
+		radiances[total_length - 1] += alphas[e] * bsdf * geometry_term(&erec[e], &light_rec) * mat_emitted(rec_mat(s, &light_rec), b) / light_pdf_area;
+	}
+	for (size_t e = 0; e < K; e++) { /* s >= 1, t > 1, :722-762 */
+		for (size_t l = 0; l < L; l++) {
+			size_t total_length = (e + 1) + (l + 2);
+			path_numbers[total_length - 1]++;
+			v3 to = vsub(lrec[l].p, erec[e].p);
+			hitrec tmp;
+			st->shadow_rays++;
+			if (world_hit(s, WORLD_MODE, erec[e].p, vunit(to), 0.001, vlen(to) - 0.001, &tmp)) continue; /* Occluded = closest hit, hittable.h:34-40 */
+			double eye_bsdf, light_bsdf;
+			{
+				onb uvw = onb_from_w(erec[e].normal);
+				v3 vi = onb_w2l(&uvw, vunit(to));
+				v3 vo = onb_w2l(&uvw, vneg(eray_d[e]));
+				eye_bsdf = mat_bsdf(rec_mat(s, &erec[e]), vi, b->central_wl, vo);
+			}
+			{
+				onb uvw = onb_from_w(lrec[l].normal);
+				v3 vi = onb_w2l(&uvw, vneg(lray_d[l]));
+				v3 vo = onb_w2l(&uvw, vunit(vsub(erec[e].p, lrec[l].p)));
+				light_bsdf = mat_bsdf(rec_mat(s, &lrec[l]), vi, b->central_wl, vo);
+			}
+			radiances[total_length - 1] += alphas[e] * betas[l] * eye_bsdf * light_bsdf * geometry_term(&erec[e], &lrec[l]) * light_value /
+			                               (light_pdf_area * light_dir_pdf_projected);
+		}
+	}
+	double radiance = 0.0;
+	for (size_t i = 0; i < n_len; i++) {
+		if (path_numbers[i] == 0) continue;
+		radiance += radiances[i] / (double)path_numbers[i];
+	}
+	return radiance;
+}
+
 static double radiance_dispatch(const orc_scene *s, int algorithm, v3 o, v3 d, const band *b, uint64_t *rng, orc_render_stats *st)
 {
 	switch (algorithm) { /* renderer.cpp:96-112 */
 	case ORC_ALG_NAIVE: return naive_path_tracing(s, o, d, b, rng, st);
 	case ORC_ALG_NEE: return nee_path_tracing(s, o, d, b, rng, st);
+	case ORC_ALG_NAIVE_BDPT: return naive_bdpt(s, o, d, b, rng, st);
+	case ORC_ALG_MIS_BDPT: return 0.0; /* MISBDPT, renderer.cpp:775-778 */
 	default: return mis_path_tracing(s, o, d, b, rng, st);
 	}
 }

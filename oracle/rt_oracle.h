@@ -140,7 +140,7 @@ double orc_environment_lookup(const uint8_t *tex, int w, int h, int bpp, double 
                               double t, double central_wl); /* renderer.cpp:180-191 */
 uint64_t orc_scene_n_lights(const orc_scene *s);
 
-enum { ORC_ALG_NAIVE = 0, ORC_ALG_NEE = 1, ORC_ALG_MIS = 2 }; /* renderer.h:12-18 */
+enum { ORC_ALG_NAIVE = 0, ORC_ALG_NEE = 1, ORC_ALG_MIS = 2, ORC_ALG_NAIVE_BDPT = 3, ORC_ALG_MIS_BDPT = 4 }; /* renderer.h:12-18 */
 
 typedef struct orc_render_stats {
 	uint64_t closest_rays, shadow_rays, samples;

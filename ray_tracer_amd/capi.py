@@ -9,7 +9,7 @@ MISS = 0xFFFFFFFF
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NO_LIGHTS, ERR_NO_MATERIAL, ERR_MESH = 0, -1, -2, -3, -4, -5, -6
 BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH, BUILDER_AUTO = 0, 1, 2
 MAT_NONE, MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_COLORED_METAL = range(6)
-ALG_NAIVE, ALG_NEE, ALG_MIS = 0, 1, 2
+ALG_NAIVE, ALG_NEE, ALG_MIS, ALG_NAIVE_BDPT, ALG_MIS_BDPT = 0, 1, 2, 3, 4
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmi355rt.so")
 

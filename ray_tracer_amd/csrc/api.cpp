@@ -332,8 +332,8 @@ int rt_render_begin(rt_context *ctx, int nx, int ny, int ns, int spectral_sample
 		return set_err(ctx, RT_ERR_INVALID, "rt_render_begin: mesh, materials and camera must be set first");
 	if (nx <= 0 || ny <= 0 || ns <= 0 || spectral_samples <= 0 || spectral_samples > 65535)
 		return set_err(ctx, RT_ERR_INVALID, "rt_render_begin: nx, ny, ns must be positive and spectral_samples in 1..65535");
-	if (algorithm < RT_ALG_NAIVE || algorithm > RT_ALG_MIS)
-		return set_err(ctx, RT_ERR_INVALID, "rt_render_begin: algorithm must be Naive, NEE or MIS (the bidirectional integrators are not implemented)");
+	if (algorithm < RT_ALG_NAIVE || algorithm > RT_ALG_MIS_BDPT)
+		return set_err(ctx, RT_ERR_INVALID, "rt_render_begin: unknown algorithm");
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	std::string err;
 	hipError_t e = render_begin(ctx->render, ctx->camera, nx, ny, ns, spectral_samples, algorithm, seed, d_film, ctx->stream, err);

@@ -9,6 +9,7 @@
 // being summed per path and added at the end; a NaN term is dropped on its own where the reference
 // drops the whole sample (renderer.cpp:115).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -97,7 +98,7 @@ struct Impl {
 	const uint32_t *tri_face = nullptr, *face_object = nullptr;
 	DevCamera cam{};
 	// queues
-	uint64_t capacity = 0;
+	uint64_t capacity = 0, conn_capacity = 0;
 	rt_ray *rays[2] = {nullptr, nullptr};
 	PathState *state[2] = {nullptr, nullptr};
 	rt_hit *hits = nullptr;
@@ -109,6 +110,12 @@ struct Impl {
 	Counters *h_counters = nullptr; // pinned mirror, filled by asynchronous copies
 	hipEvent_t ev[kMaxBounces + 2] = {};
 	std::vector<float> film_host;
+	// NaiveBDPT: per-sample records, subpath vertices, connection slot counts and offsets
+	void *bdpt_samples = nullptr, *bdpt_verts = nullptr, *bdpt_scan_tmp = nullptr;
+	uint32_t *bdpt_counts = nullptr, *bdpt_offsets = nullptr;
+	unsigned long long *bdpt_pairs = nullptr;
+	uint64_t bdpt_capacity = 0;
+	size_t bdpt_scan_bytes = 0;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -230,8 +237,9 @@ __device__ __forceinline__ float cfresnel(float cos_theta, float nre, float nim)
 }
 
 // NodeMaterial::SampleBSDF for ImportanceType rays (materialnode.cpp:1758-1766 and the node bodies)
+// light_type: RayType LightType (the light subpath of NaiveBDPT, renderer.cpp:589); only the dielectric's refraction tells them apart
 __device__ __forceinline__ bool mat_sample(const DevMaterial &m, f3 normal, const Onb &uvw, f3 vo, int bin, uint64_t &rng,
-                                           f3 &vi, float &ratio, float &pdfval)
+                                           f3 &vi, float &ratio, float &pdfval, bool light_type = false)
 {
 	switch (m.type) {
 	case RT_MAT_LAMBERTIAN: { // :262-276; CosinePdf builds its own frame from rec.normal (pdf.cpp:36-46,70-84)
@@ -263,7 +271,7 @@ __device__ __forceinline__ bool mat_sample(const DevMaterial &m, f3 normal, cons
 			float sin_o = sqrtf(1.0f - cos_o * cos_o), sin_t = sin_o / rel, cos_t = sqrtf(1.0f - sin_t * sin_t);
 			f3 h = unit(F3(vo.x, vo.y, 0.0f));
 			vi = F3(-sin_t * h.x, -sin_t * h.y, -cos_t * nz - sin_t * h.z);
-			ratio = surface_scale / (rel * rel * rel) / cos_t;
+			ratio = light_type ? surface_scale * (rel * rel * rel) / cos_t : surface_scale / (rel * rel * rel) / cos_t; // :399-403
 		}
 		return true;
 	}
@@ -634,6 +642,8 @@ __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh
 	film_add(film, c.pixel, bd, add);
 }
 
+#include "render_bdpt.inc"
+
 // ---------------------------------------------------------------------------------------------
 // tonemap (renderer.cpp:124-143, spectrum.cpp:164-199)
 // ---------------------------------------------------------------------------------------------
@@ -743,6 +753,7 @@ void free_queues(Impl &im)
 	if (im.conn_any) (void)hipFree(im.conn_any);
 	im.hits = nullptr; im.conn_rays = nullptr; im.conn = nullptr; im.conn_hits = nullptr; im.conn_any = nullptr;
 	im.capacity = 0;
+	im.conn_capacity = 0;
 }
 
 } // namespace
@@ -880,6 +891,7 @@ static hipError_t ensure_queues(Impl &im, uint64_t cap, std::string &err)
 	HIP_TRY(hipMalloc((void **)&im.conn_hits, 2 * cap * sizeof(rt_hit)));
 	HIP_TRY(hipMalloc((void **)&im.conn_any, 2 * cap));
 	im.capacity = cap;
+	im.conn_capacity = 2 * cap;
 	return hipSuccess;
 }
 
@@ -992,15 +1004,146 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 	return hipSuccess;
 }
 
+static void free_bdpt(Impl &im)
+{
+	void *ptrs[] = {im.bdpt_samples, im.bdpt_verts, im.bdpt_scan_tmp, im.bdpt_counts, im.bdpt_offsets, im.bdpt_pairs};
+	for (void *p : ptrs) if (p) (void)hipFree(p);
+	im.bdpt_samples = im.bdpt_verts = im.bdpt_scan_tmp = nullptr;
+	im.bdpt_counts = im.bdpt_offsets = nullptr;
+	im.bdpt_pairs = nullptr;
+	im.bdpt_capacity = 0;
+}
+
+static hipError_t ensure_bdpt(Impl &im, uint64_t cap, hipStream_t stream, std::string &err)
+{
+	if (cap <= im.bdpt_capacity) return hipSuccess;
+	free_bdpt(im);
+	HIP_TRY(hipMalloc(&im.bdpt_samples, cap * sizeof(BdptSample)));
+	HIP_TRY(hipMalloc(&im.bdpt_verts, cap * 2 * kBdptMax * sizeof(BdptVertex)));
+	HIP_TRY(hipMalloc((void **)&im.bdpt_counts, cap * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **)&im.bdpt_offsets, cap * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **)&im.bdpt_pairs, sizeof(unsigned long long)));
+	im.bdpt_scan_bytes = 0;
+	HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, im.bdpt_scan_bytes, im.bdpt_counts, im.bdpt_offsets, (int)cap, stream));
+	HIP_TRY(hipMalloc(&im.bdpt_scan_tmp, std::max<size_t>(im.bdpt_scan_bytes, 1)));
+	im.bdpt_capacity = cap;
+	return hipSuccess;
+}
+
+// one batch of NaiveBDPT samples (see render_bdpt.inc for the stages)
+static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err)
+{
+	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_paths = npix * (uint64_t)n_samples;
+	const uint32_t n = (uint32_t)n_paths;
+	const DeviceShade sh = make_shade(im);
+	Profiler nop, &prof = rs.profiler ? *rs.profiler : nop;
+	BdptSample *samples = static_cast<BdptSample *>(im.bdpt_samples);
+	BdptVertex *verts = static_cast<BdptVertex *>(im.bdpt_verts);
+	const unsigned blocks_n = (unsigned)((n_paths + kBlock - 1) / kBlock);
+	prof.begin(Profiler::GENERATE, n_paths, stream);
+	hipLaunchKernelGGL(k_generate, dim3(blocks_n), dim3(kBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns, first_sample,
+	                   n_paths, rs.seed, 0.001f, im.rays[0], im.state[0]);
+	hipLaunchKernelGGL(k_bdpt_init, dim3(blocks_n), dim3(kBlock), 0, stream, n, im.state[0], samples);
+	prof.end(stream);
+	HIP_TRY(hipGetLastError());
+	rs.camera_samples += n_paths;
+	// a subpath: trace, walk, repeat until no walker is left; the count of survivors is read back every bounce
+	auto walk = [&](bool light) -> hipError_t {
+		uint64_t live = n_paths;
+		int cur = 0;
+		for (int bounce = 0; live > 0; bounce++) {
+			if (bounce > 4 * kBdptMax) { err = "NaiveBDPT: a subpath does not end"; return hipErrorUnknown; }
+			HIP_TRY(hipMemsetAsync(im.counters, 0, 2 * sizeof(Counters), stream));
+			HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)im.counters, (int)live, 1, stream));
+			const uint32_t *n_live = reinterpret_cast<const uint32_t *>(&im.counters[0]);
+			prof.begin(Profiler::CLOSEST, live, stream);
+			HIP_TRY(launch_trace_closest(geom, im.rays[cur], live, im.hits, nullptr, stream, n_live));
+			prof.end(stream);
+			prof.begin(Profiler::SHADE, live, stream);
+			const dim3 grid((unsigned)((live + kShadeBlock - 1) / kShadeBlock));
+			if (light)
+				hipLaunchKernelGGL((k_bdpt_walk<true>), grid, dim3(kShadeBlock), 0, stream, sh, n_live, im.rays[cur], im.state[cur], im.hits,
+				                   im.rays[cur ^ 1], im.state[cur ^ 1], &im.counters[1], samples, verts, rs.d_film);
+			else
+				hipLaunchKernelGGL((k_bdpt_walk<false>), grid, dim3(kShadeBlock), 0, stream, sh, n_live, im.rays[cur], im.state[cur], im.hits,
+				                   im.rays[cur ^ 1], im.state[cur ^ 1], &im.counters[1], samples, verts, rs.d_film);
+			prof.end(stream);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipMemcpyAsync(&im.h_counters[1], &im.counters[1], sizeof(Counters), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+			rs.closest_rays += live;
+			live = (uint32_t)im.h_counters[1].tails;
+			cur ^= 1;
+		}
+		return hipSuccess;
+	};
+	hipError_t e = walk(false);
+	if (e != hipSuccess) return e;
+	prof.begin(Profiler::GENERATE, n_paths, stream);
+	hipLaunchKernelGGL(k_bdpt_light_start, dim3(blocks_n), dim3(kBlock), 0, stream, sh, n, samples, im.rays[0], im.state[0]);
+	prof.end(stream);
+	HIP_TRY(hipGetLastError());
+	e = walk(true);
+	if (e != hipSuccess) return e;
+	// connection slots: count, scan, generate, trace, evaluate
+	HIP_TRY(hipMemsetAsync(im.bdpt_pairs, 0, sizeof(unsigned long long), stream));
+	hipLaunchKernelGGL(k_bdpt_count, dim3(blocks_n), dim3(kBlock), 0, stream, n, samples, im.bdpt_counts, im.bdpt_pairs);
+	HIP_TRY(hipGetLastError());
+	size_t scan_bytes = im.bdpt_scan_bytes;
+	HIP_TRY(hipcub::DeviceScan::ExclusiveSum(im.bdpt_scan_tmp, scan_bytes, im.bdpt_counts, im.bdpt_offsets, (int)n, stream));
+	uint32_t last_off = 0, last_cnt = 0;
+	unsigned long long pairs = 0;
+	HIP_TRY(hipMemcpyAsync(&last_off, im.bdpt_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipMemcpyAsync(&last_cnt, im.bdpt_counts + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipMemcpyAsync(&pairs, im.bdpt_pairs, sizeof(pairs), hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipStreamSynchronize(stream));
+	const uint64_t total = (uint64_t)last_off + last_cnt;
+	if (total >= (1ull << 32)) { err = "NaiveBDPT: more than 2^32 connections in one batch"; return hipErrorInvalidValue; }
+	if (total > im.conn_capacity) { // about 4.6 slots per sample on the Cornell box; grown on demand, kept for later batches
+		const uint64_t want = total + total / 4;
+		if (im.conn_rays) (void)hipFree(im.conn_rays);
+		if (im.conn) (void)hipFree(im.conn);
+		if (im.conn_hits) (void)hipFree(im.conn_hits);
+		if (im.conn_any) (void)hipFree(im.conn_any);
+		im.conn_rays = nullptr; im.conn = nullptr; im.conn_hits = nullptr; im.conn_any = nullptr;
+		im.conn_capacity = 0;
+		HIP_TRY(hipMalloc((void **)&im.conn_rays, want * sizeof(rt_ray)));
+		HIP_TRY(hipMalloc((void **)&im.conn, want * sizeof(ConnRec)));
+		HIP_TRY(hipMalloc((void **)&im.conn_hits, want * sizeof(rt_hit)));
+		HIP_TRY(hipMalloc((void **)&im.conn_any, want));
+		im.conn_capacity = want;
+	}
+	if (total == 0) return hipSuccess;
+	prof.begin(Profiler::SHADE, n_paths, stream);
+	hipLaunchKernelGGL(k_bdpt_connect_gen, dim3(blocks_n), dim3(kBlock), 0, stream, sh, n, samples, verts, im.bdpt_offsets, im.conn_rays, im.conn);
+	prof.end(stream);
+	HIP_TRY(hipGetLastError());
+	prof.begin(Profiler::CLOSEST, total, stream);
+	HIP_TRY(launch_trace_closest(geom, im.conn_rays, total, im.conn_hits, nullptr, stream, nullptr));
+	prof.end(stream);
+	prof.begin(Profiler::CONNECT, total, stream);
+	hipLaunchKernelGGL(k_bdpt_connect_eval, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sh, (uint32_t)total, im.conn_rays,
+	                   im.conn, im.conn_hits, rs.d_film);
+	prof.end(stream);
+	HIP_TRY(hipGetLastError());
+	rs.closest_rays += total - pairs; // slots whose term was zero are counted although their ray is answered at once
+	rs.any_rays += pairs;
+	return hipSuccess;
+}
+
 hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err)
 {
 	Impl &im = *impl_of(rs);
 	const uint64_t npix = (uint64_t)rs.nx * rs.ny;
 	// samples per batch: large batches amortise the nearly empty late bounces; queue memory is about 380 bytes per path (<= 2^25 paths, 12.7 GB)
-	uint64_t per_batch = std::max<uint64_t>(1, (1ull << 25) / std::max<uint64_t>(npix, 1));
+	if (rs.algorithm == RT_ALG_MIS_BDPT) return hipSuccess; // MISBDPT returns 0 for every sample (renderer.cpp:775-778): the film stays empty
+	const bool bdpt = rs.algorithm == RT_ALG_NAIVE_BDPT;
+	// NaiveBDPT keeps 16 subpath vertices per sample (832 bytes with the sample record): 2^22 samples per batch
+	uint64_t per_batch = std::max<uint64_t>(1, (1ull << (bdpt ? 22 : 25)) / std::max<uint64_t>(npix, 1));
 	if (npix * per_batch >= (1ull << 31)) per_batch = 1;
 	if (npix >= (1ull << 31)) { err = "image too large for 32-bit path indices"; return hipErrorInvalidValue; }
 	HIP_TRY(ensure_queues(im, npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1)), err));
+	if (bdpt) HIP_TRY(ensure_bdpt(im, npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1)), stream, err));
 	int s = first_sample, end = first_sample + n_samples;
 	while (s < end) {
 		int b = (int)std::min<uint64_t>(per_batch, (uint64_t)(end - s));
@@ -1008,6 +1151,7 @@ hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample
 		switch (rs.algorithm) {
 		case RT_ALG_NAIVE: e = run_batch<RT_ALG_NAIVE>(rs, im, geom, s, b, stream, err); break;
 		case RT_ALG_NEE: e = run_batch<RT_ALG_NEE>(rs, im, geom, s, b, stream, err); break;
+		case RT_ALG_NAIVE_BDPT: e = run_batch_bdpt(rs, im, geom, s, b, stream, err); break;
 		default: e = run_batch<RT_ALG_MIS>(rs, im, geom, s, b, stream, err); break;
 		}
 		if (e != hipSuccess) return e;
@@ -1073,6 +1217,7 @@ void render_free(RenderState &rs)
 		if (im.light_faces) (void)hipFree(im.light_faces);
 		if (im.bands) (void)hipFree(im.bands);
 		if (im.env) (void)hipFree(im.env);
+		free_bdpt(im);
 		if (im.counters) {
 			(void)hipFree(im.counters);
 			for (auto &e : im.ev) if (e) (void)hipEventDestroy(e);

@@ -1,7 +1,7 @@
 // Headless driver for the host-side Renderer: what the reference's `--cli` mode does (main.cpp:54-99) plus the
 // camera set-up the GUI performs (scene.cpp:866-867), with the linear film dumped for tests.
 //   rt_cli --obj scene.obj --materials materials.json --objmatmap map.json [--width W --height H --sample S]
-//          [--algorithm naive|nee|mis] [--seed N] [--spectral 30] [--film out.f64] [--ppm out.ppm] [--records out.f64]
+//          [--algorithm naive|nee|mis|bdpt|misbdpt] [--seed N] [--spectral 30] [--film out.f64] [--ppm out.ppm] [--records out.f64]
 //          [--ply mesh.ply --ply-object NAME --ply-normals auto|file|flat|smooth]   one more object from a PLY file
 //   rt_cli --ply mesh.ply --dump-ply out.bin       host only: the parsed tables (u64 nv, nf, ni, has_normals; f64 [nv][6];
 //                                                  u64 [nf+1]; i32 [ni]) for tests
@@ -77,7 +77,7 @@ int main(int argc, char **argv)
 		r.cam.film_width = 0.024 * w / h; // scene.cpp:668
 		r.cam.SetLens(60.0, 0.4);
 		r.cam.set_Camera(dvec3(0, 0, 3), dvec3(0, 0, 2), dvec3(0, 1, 0));
-		r.algorithm_type = alg == "naive" ? Naive : (alg == "nee" ? NEE : MIS);
+		r.algorithm_type = alg == "naive" ? Naive : alg == "nee" ? NEE : alg == "bdpt" ? NaiveBDPTType : alg == "misbdpt" ? MISBDPTType : MIS;
 		r.preview_img_flag = false;
 		r.samples_per_pass = ns;
 		r.RenderImage(w, h, ns, spectral, true, false);

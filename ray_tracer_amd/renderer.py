@@ -14,7 +14,7 @@ class Renderer:
         self.ctx = capi.Context(device)
         self.obj_loader = Obj()
         self.cam = LensCamera()
-        self.algorithm_type = NaiveBDPTType  # renderer.h:33 (the GUI default; not implemented on the device)
+        self.algorithm_type = NaiveBDPTType  # renderer.h:33
         self.spectrum_img = None  # [nx*ny, 30] float64, pixel index i*ny+j (renderer.cpp:116)
         self.preview_img = None   # [nx*ny, 3] float64, gamma-encoded in [0, 1]
         self.preview_img_flag = True
@@ -81,8 +81,8 @@ class Renderer:
         self.img_updated = False
 
     def RenderImage(self, nx, ny, ns, spectral_samples, enable_openmp=True, print_progress=False):  # renderer.cpp:54-160
-        if self.algorithm_type not in (Naive, NEE, MIS):
-            raise NotImplementedError("only Naive, NEE and MIS run on the device; the bidirectional integrators do not")
+        if self.algorithm_type not in (Naive, NEE, MIS, NaiveBDPTType, MISBDPTType):
+            raise ValueError("unknown algorithm_type")
         self.rendering_runnnig = True
         self.ctx.set_camera(self.cam)
         self.ctx.render_begin(nx, ny, ns, spectral_samples, self.algorithm_type, self.seed)

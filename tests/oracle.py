@@ -8,7 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NBINS = 30
 MODE_BVH_REFERENCE, MODE_LIST, MODE_LIST_LOWEST = 0, 1, 2
-ALG_NAIVE, ALG_NEE, ALG_MIS = 0, 1, 2
+ALG_NAIVE, ALG_NEE, ALG_MIS, ALG_NAIVE_BDPT, ALG_MIS_BDPT = 0, 1, 2, 3, 4
 
 dp = C.POINTER(C.c_double)
 
