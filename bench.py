@@ -192,9 +192,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU path")
+    # rehearsal on a one-GPU box only: BENCH_REHEARSAL=1 puts every rank on device 0 and sums the films with gloo
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = capi.Context(local_rank)
 
     cpu, oracle = (None, None)
@@ -219,6 +226,11 @@ def main():
     ctx.render_sync()
     torch.cuda.synchronize()
     if world > 1:
+        # the first collective of a given size sets up rings, buffers and kernels: keep that out of the timed region
+        scratch = torch.zeros_like(film)
+        dist.all_reduce(scratch)
+        del scratch
+        torch.cuda.synchronize()
         dist.barrier()
     ctx.profile_start()
     t0 = time.perf_counter()
@@ -249,23 +261,37 @@ def main():
                 "kernel": "k_trace (closest hit)", "kernel_ms_avg": k["ms"] / max(k["launches"], 1), "launches": k["launches"],
                 "rays": k["items"], "kernel_ms_total": k["ms"], "mrays_per_s_in_kernel": k["items"] / max(k["ms"], 1e-9) / 1e3}
         tr, tr_file = recorded_traffic("r*_bench_traffic.json", "k_trace<true, false>")
-        if tr is not None:
+        default_workload = (nx, ny, spp, args.algorithm) == (1920, 1080, 16, "mis")
+        if tr is not None and default_workload:
             roof["traffic"] = tr["bytes_per_launch"]
             roof["traffic_note"] = ("bytes per launch on the memory side of the L2 (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes "
                                     "over this command, recorded in %s); far below the algorithmic bytes because the small tree stays "
                                     "in cache: only rays and hits reach HBM" % tr_file)
+        counts = None
         if cpu is not None:
-            bytes_per_ray = b_ray(cpu["cornell_nodes_per_ray"], cpu["cornell_tris_per_ray"])
+            counts = (cpu["cornell_nodes_per_ray"], cpu["cornell_tris_per_ray"], "counted in this run")
+        elif default_workload:
+            # no CPU leg (N > 1 or --no-cpu): the work-unit counts of the same scene, camera and integrator from the committed N = 1 run
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+            if files:
+                prev = json.load(open(files[-1])).get("roofline", {})
+                if prev.get("nodes_per_ray") is not None:
+                    counts = (prev["nodes_per_ray"], prev["tris_per_ray"], "from " + os.path.relpath(files[-1], ROOT))
+        if counts is not None:
+            cpu_counts = {"cornell_nodes_per_ray": counts[0], "cornell_tris_per_ray": counts[1]}
+            roof["work_unit_counts"] = counts[2]
+            bytes_per_ray = b_ray(cpu_counts["cornell_nodes_per_ray"], cpu_counts["cornell_tris_per_ray"])
             roof["achieved"] = k["items"] * bytes_per_ray / (k["ms"] * 1e-3) / 1e9
             roof["frac"] = roof["achieved"] * 1e9 / HBM_PEAK
             roof["bytes_per_ray"] = bytes_per_ray
             roof["algorithmic_bytes_per_launch"] = k["items"] / max(k["launches"], 1) * bytes_per_ray
-            roof["nodes_per_ray"], roof["tris_per_ray"] = cpu["cornell_nodes_per_ray"], cpu["cornell_tris_per_ray"]
+            roof["nodes_per_ray"], roof["tris_per_ray"] = cpu_counts["cornell_nodes_per_ray"], cpu_counts["cornell_tris_per_ray"]
         line = {
             "metric": "spp/s at 1080p (Cornell box, NEE+MIS wavefront integrator); the incoherent closest-hit Mrays/s half of the metric is under aux",
             "value": args.steps * spp * world / dt, "unit": "spp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 triangle test, f32 box test and shading", "data": "synthetic",
+            "dtype": "f64", "dtype_detail": "f64 triangle test (the reference's arithmetic), f32 conservative box tests and shading", "data": "synthetic",
             "config": {"workload": "Cornell box (example/cornell_box_triangulated.obj + materials.json) %dx%d, %s, 30 spectral bands, "
                                    "%d spp per step, %d spp timed per GPU" % (nx, ny, {"mis": "NEE+MIS", "nee": "NEE", "naive": "naive path tracing",
                                                                                       "bdpt": "NaiveBDPT"}[args.algorithm], spp, args.steps * spp),
