@@ -448,6 +448,9 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DeviceShade sh, const uin
                                                   Counters *__restrict__ counters, float *__restrict__ film)
 {
 	const uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
+	// grids are sized from an upper bound of the queue length (the count of two bounces ago): most workgroups of a
+	// late bounce lie wholly beyond the queue and leave before the slot reservation below (uniform per workgroup)
+	if (blockIdx.x * kShadeBlock >= *n_dev) return;
 	const bool live = idx < *n_dev;
 	bool survive = false, want_c0 = false, want_c1 = false;
 	rt_ray nr{}, cr0{}, cr1{};
