@@ -144,6 +144,31 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh);
  * environment variable MI355RT_BUILDER=host|device overrides it. */
 typedef enum rt_builder { RT_BUILDER_HOST_SAH = 0, RT_BUILDER_DEVICE_LBVH = 1, RT_BUILDER_AUTO = 2 } rt_builder;
 int rt_set_builder(rt_context *ctx, int builder);
+/* Per-hit material graphs.  replaces: the Compute() chains that NodeMaterial::{SampleBSDF,BSDF,PDF,Emitted} run with
+ * Argument{rec.vt} on every call (materialnode.cpp:1758-1795) when the albedo / color slot of a Lambertian, ColoredMetal or
+ * DiffuseLight node is fed by nodes that read the hit's texture coordinate.  The host compiles such a graph to a postfix
+ * program of (op, arg) pairs; values are vectors or spectra, at most four deep:
+ *   0 SPEC k     push spectra[k]                      (SpectrumNode and folded constant sub-graphs)
+ *   1 VEC k      push vectors[k]                      (RGBColorNode, :931-936)
+ *   2 UV         push rec.vt                          (UVNode, :893-896)
+ *   3 ZERO_S, 4 ZERO_V  push zeros                    (an unconnected input)
+ *   5 IMAGE k    uv -> rgb of textures[k]             (ImageTextureNode, :1001-1018)
+ *   6 CHECKER k  uv -> (1,1,1) or (0,0,0), size scalars[k]  (CheckerboardNode, :1046-1063)
+ *   7 RGB2SPEC   rgb -> spectrum                      (RGBtoSpectrumNode, :949-957)
+ *   8 ADD_S, 9 MUL_S, 10 ADD_V, 11 MUL_V              (AdditionNode :1083-1109, MultiplicationNode :1179-1203)
+ * A program must leave exactly one spectrum.  Call after rt_upload_materials (which drops earlier programs); the record's
+ * `a` is ignored for objects that have a program.  graphs == NULL or n_programs == 0 removes all programs. */
+typedef struct rt_texture { const uint8_t *texels; int32_t width, height, bpp; } rt_texture; /* height rows of width texels, bpp >= 3 bytes each */
+typedef struct rt_graph_program { uint32_t object, code_begin, code_len; } rt_graph_program; /* in pairs */
+typedef struct rt_material_graphs {
+	const rt_graph_program *programs; uint32_t n_programs;
+	const uint32_t *code; uint32_t n_code;        /* n_code (op, arg) pairs */
+	const double *spectra; uint32_t n_spectra;    /* [n][RT_NBINS] */
+	const double *vectors; uint32_t n_vectors;    /* [n][3] */
+	const double *scalars; uint32_t n_scalars;
+	const rt_texture *textures; uint32_t n_textures;
+} rt_material_graphs;
+int rt_upload_material_graphs(rt_context *ctx, const rt_material_graphs *graphs);
 /* replaces: the globals env_mapping_texture / env_mapping_width / env_mapping_height / env_mapping_bpp / env_brightness
  * (scene.h:20-22, filled by stbi_load at scene.cpp:245) that NaivePathTracing reads when a ray leaves the scene
  * (renderer.cpp:175-193).  texels: height rows of width texels, bpp (3 or 4) bytes each, copied; NULL removes the

@@ -461,6 +461,12 @@ struct orc_scene {
 	orc_material *mats; /* per object */
 	uint64_t *lights;   /* polygon ids */
 	uint64_t n_lights;
+	/* per-hit material graphs: program of slot a (albedo / color) per object, shared tables */
+	uint32_t *prog_begin, *prog_len; /* per object; len 0: the constant record */
+	uint32_t *code; uint32_t n_code; /* (op, arg) pairs */
+	double *g_spectra, *g_vectors, *g_scalars;
+	uint32_t n_g_spectra, n_g_vectors, n_g_scalars, n_g_textures;
+	uint8_t **g_tex; int *g_tex_w, *g_tex_h, *g_tex_bpp;
 	/* environment texture (globals of scene.h:20-22) */
 	uint8_t *env;
 	int env_w, env_h, env_bpp;
@@ -557,6 +563,7 @@ orc_scene *orc_scene_create(const double *v, uint64_t n_v, const double *vt, uin
 	return s;
 }
 
+static void free_graphs(orc_scene *s);
 void orc_scene_free(orc_scene *s)
 {
 	if (!s) return;
@@ -564,6 +571,7 @@ void orc_scene_free(orc_scene *s)
 	free(s->pv); free(s->pvt); free(s->pn); free(s->face_normal); free(s->object_id);
 	free(s->polygon_area); free(s->tri_cum); free(s->tri_poly); free(s->poly_box);
 	free(s->nodes); free(s->mats); free(s->lights); free(s->env);
+	free_graphs(s);
 	free(s);
 }
 uint64_t orc_scene_n_polygons(const orc_scene *s) { return s->n_polys; }
@@ -594,12 +602,13 @@ void orc_scene_get_triangles(const orc_scene *s, double *v9, double *nf3, uint32
 typedef struct {
 	double t;
 	v3 p, normal;
+	v3 vt;        /* rec.vt, object.cpp:258 */
 	int64_t poly; /* rec.hit_object */
 	int64_t tri;  /* which fan triangle accepted the hit */
 } hitrec;
 
 static inline int hit_triangle(v3 o, v3 d, double t_min, double t_max, v3 v0, v3 v1, v3 v2, v3 n0, v3 n1, v3 n2,
-                               v3 face_normal, hitrec *rec) /* object.cpp:238-284 */
+                               v3 vt0, v3 vt1, v3 vt2, v3 face_normal, hitrec *rec) /* object.cpp:238-284 */
 {
 	double t = vdot(vsub(v0, o), face_normal) / vdot(d, face_normal);
 	if (!(t >= t_min && t <= t_max))
@@ -613,6 +622,7 @@ static inline int hit_triangle(v3 o, v3 d, double t_min, double t_max, v3 v0, v3
 		rec->t = t;
 		rec->p = p;
 		rec->normal = vdiv(vadd(vadd(vscale(vlen(result1), n0), vscale(vlen(result2), n1)), vscale(vlen(result0), n2)), tri_area);
+		rec->vt = vdiv(vadd(vadd(vscale(vlen(result1), vt0), vscale(vlen(result2), vt1)), vscale(vlen(result0), vt2)), tri_area); /* :258 */
 		return 1;
 	}
 	return 0;
@@ -623,7 +633,7 @@ static inline int polygon_hit(const orc_scene *s, uint64_t f, v3 o, v3 d, double
 	uint64_t b = s->poly_begin[f], n = s->poly_begin[f + 1] - b;
 	for (uint64_t i = 1; i + 1 < n; i++) {
 		if (hit_triangle(o, d, t_min, t_max, s->pv[b], s->pv[b + i], s->pv[b + i + 1], s->pn[b], s->pn[b + i],
-		                 s->pn[b + i + 1], s->face_normal[f], rec)) {
+		                 s->pn[b + i + 1], s->pvt[b], s->pvt[b + i], s->pvt[b + i + 1], s->face_normal[f], rec)) {
 			rec->poly = (int64_t)f;
 			rec->tri = (int64_t)(s->tri_begin[f] + i - 1);
 			return 1;
@@ -930,7 +940,7 @@ uint64_t orc_trace_bvh2(const orc_scene *s, const void *nodes_v, uint64_t n_node
 					hitrec rec;
 					ntt++;
 					if (hit_triangle(o, d, t_min, t_best, s->pv[b], s->pv[b + fi], s->pv[b + fi + 1], s->pn[b],
-					                 s->pn[b + fi], s->pn[b + fi + 1], s->face_normal[f], &rec)) {
+					                 s->pn[b + fi], s->pn[b + fi + 1], s->pvt[b], s->pvt[b + fi], s->pvt[b + fi + 1], s->face_normal[f], &rec)) {
 						if (best_tri < 0 || rec.t < t_best || (int64_t)t < best_tri) { /* tie -> lowest fan triangle */
 							best = rec;
 							best.poly = (int64_t)f;
@@ -957,6 +967,56 @@ uint64_t orc_trace_bvh2(const orc_scene *s, const void *nodes_v, uint64_t n_node
 /* ======================================================================================= */
 /* Materials (materialnode.cpp) and Renderer::LoadMaterials (renderer.cpp:24-44)            */
 /* ======================================================================================= */
+static void free_graphs(orc_scene *s)
+{
+	free(s->prog_begin); free(s->prog_len); free(s->code); free(s->g_spectra); free(s->g_vectors); free(s->g_scalars);
+	for (uint32_t i = 0; i < s->n_g_textures; i++) free(s->g_tex[i]);
+	free(s->g_tex); free(s->g_tex_w); free(s->g_tex_h); free(s->g_tex_bpp);
+	s->prog_begin = s->prog_len = s->code = NULL;
+	s->g_spectra = s->g_vectors = s->g_scalars = NULL;
+	s->g_tex = NULL; s->g_tex_w = s->g_tex_h = s->g_tex_bpp = NULL;
+	s->n_code = s->n_g_spectra = s->n_g_vectors = s->n_g_scalars = s->n_g_textures = 0;
+}
+
+/* per-hit graphs for slot a of some objects (see graph_eval); programs: (object, begin, len) triples; textures given as parallel arrays.
+ * Parity unpinned: materialnode.cpp does not compile here. */
+int orc_scene_set_material_graphs(orc_scene *s, const uint32_t *programs, uint32_t n_programs, const uint32_t *code, uint32_t n_code,
+                                  const double *spectra, uint32_t n_spectra, const double *vectors, uint32_t n_vectors,
+                                  const double *scalars, uint32_t n_scalars, const uint8_t *const *tex, const int *tex_w,
+                                  const int *tex_h, const int *tex_bpp, uint32_t n_textures)
+{
+	free_graphs(s);
+	if (n_programs == 0) return 0;
+	s->prog_begin = (uint32_t *)calloc(s->n_objects, sizeof(uint32_t));
+	s->prog_len = (uint32_t *)calloc(s->n_objects, sizeof(uint32_t));
+	for (uint32_t i = 0; i < n_programs; i++) {
+		if (programs[3 * i] >= s->n_objects || programs[3 * i + 1] + programs[3 * i + 2] > n_code) return -1;
+		s->prog_begin[programs[3 * i]] = programs[3 * i + 1];
+		s->prog_len[programs[3 * i]] = programs[3 * i + 2];
+	}
+	s->code = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (n_code ? n_code : 1));
+	memcpy(s->code, code, sizeof(uint32_t) * 2 * n_code);
+	s->n_code = n_code;
+	s->g_spectra = (double *)malloc(sizeof(double) * ORC_NBINS * (n_spectra ? n_spectra : 1));
+	memcpy(s->g_spectra, spectra, sizeof(double) * ORC_NBINS * n_spectra);
+	s->g_vectors = (double *)malloc(sizeof(double) * 3 * (n_vectors ? n_vectors : 1));
+	memcpy(s->g_vectors, vectors, sizeof(double) * 3 * n_vectors);
+	s->g_scalars = (double *)malloc(sizeof(double) * (n_scalars ? n_scalars : 1));
+	memcpy(s->g_scalars, scalars, sizeof(double) * n_scalars);
+	s->n_g_spectra = n_spectra; s->n_g_vectors = n_vectors; s->n_g_scalars = n_scalars; s->n_g_textures = n_textures;
+	s->g_tex = (uint8_t **)calloc(n_textures ? n_textures : 1, sizeof(uint8_t *));
+	s->g_tex_w = (int *)calloc(n_textures ? n_textures : 1, sizeof(int));
+	s->g_tex_h = (int *)calloc(n_textures ? n_textures : 1, sizeof(int));
+	s->g_tex_bpp = (int *)calloc(n_textures ? n_textures : 1, sizeof(int));
+	for (uint32_t i = 0; i < n_textures; i++) {
+		size_t bytes = (size_t)tex_w[i] * tex_h[i] * tex_bpp[i];
+		s->g_tex[i] = (uint8_t *)malloc(bytes);
+		memcpy(s->g_tex[i], tex[i], bytes);
+		s->g_tex_w[i] = tex_w[i]; s->g_tex_h[i] = tex_h[i]; s->g_tex_bpp[i] = tex_bpp[i];
+	}
+	return 0;
+}
+
 /* stands for stbi_load into the globals env_mapping_texture/width/height/bpp and env_brightness (scene.cpp:245, scene.h:20-22);
  * tex == NULL removes the environment */
 int orc_scene_set_environment(orc_scene *s, const uint8_t *tex, int w, int h, int bpp, double brightness)
@@ -1176,7 +1236,68 @@ static double geometry_term(const hitrec *rec0, const hitrec *rec1) /* renderer.
 	return fabs(vdot(dir, rec0->normal) * vdot(dir, rec1->normal) / vlen2(v));
 }
 
-static inline const orc_material *rec_mat(const orc_scene *s, const hitrec *rec) { return &s->mats[s->object_id[rec->poly]]; }
+/* ---- per-hit material graphs: the Compute() chains of materialnode.cpp that read Argument::vt, as a postfix program.
+ * Ops (arg): 0 SPEC k  push spectrum k | 1 VEC k  push vector k | 2 UV  push rec.vt (UVNode, :893-896) | 3 ZERO_S | 4 ZERO_V |
+ * 5 IMAGE k  uv -> texel rgb (ImageTextureNode, :1001-1018) | 6 CHECKER k  uv -> 0/1 with size scalars[k] (:1046-1063) |
+ * 7 RGB2SPEC (spectrum.cpp:219-232) | 8 ADD_S | 9 MUL_S | 10 ADD_V | 11 MUL_V (elementwise, vec3.h:93) */
+typedef struct { int is_vec; double s[ORC_NBINS]; v3 v; } gval;
+static void graph_eval(const orc_scene *s, uint32_t begin, uint32_t len, v3 vt, double out[ORC_NBINS])
+{
+	gval st[16];
+	int sp = 0;
+	for (uint32_t pc = begin; pc < begin + len; pc++) {
+		uint32_t op = s->code[2 * pc], arg = s->code[2 * pc + 1];
+		switch (op) {
+		case 0: st[sp].is_vec = 0; memcpy(st[sp].s, s->g_spectra + (size_t)arg * ORC_NBINS, sizeof(double) * ORC_NBINS); sp++; break;
+		case 1: st[sp].is_vec = 1; st[sp].v = vload(s->g_vectors + 3 * (size_t)arg); sp++; break;
+		case 2: st[sp].is_vec = 1; st[sp].v = vt; sp++; break;
+		case 3: st[sp].is_vec = 0; memset(st[sp].s, 0, sizeof(st[sp].s)); sp++; break;
+		case 4: st[sp].is_vec = 1; st[sp].v = V(0, 0, 0); sp++; break;
+		case 5: { /* the reference reads past the texture for uv outside [0, 1) (undefined); such an address reads the nearest end */
+			v3 uv = st[sp - 1].v;
+			int w = s->g_tex_w[arg], h = s->g_tex_h[arg], bpp = s->g_tex_bpp[arg];
+			int x = (int)((double)w * uv.e[0]);
+			int y = (int)((double)h * (1.0 - uv.e[1]));
+			long idx = (long)x + (long)y * w;
+			if (idx < 0) idx = 0;
+			if (idx > (long)w * h - 1) idx = (long)w * h - 1;
+			const uint8_t *t = s->g_tex[arg] + (long)bpp * idx;
+			st[sp - 1].v = V((double)t[0] / 255.0, (double)t[1] / 255.0, (double)t[2] / 255.0);
+			break;
+		}
+		case 6: {
+			v3 uv = st[sp - 1].v;
+			double size = s->g_scalars[arg];
+			int x = (int)((uv.e[0] - fmod(uv.e[0], size)) / size);
+			int y = (int)((uv.e[1] - fmod(uv.e[1], size)) / size);
+			st[sp - 1].v = (x % 2 == y % 2) ? V(1.0, 1.0, 1.0) : V(0.0, 0.0, 0.0);
+			break;
+		}
+		case 7: { double rgb[3]; vstore(rgb, st[sp - 1].v); st[sp - 1].is_vec = 0; orc_rgb_to_spectrum(rgb, st[sp - 1].s); break; }
+		case 8: for (int i = 0; i < ORC_NBINS; i++) st[sp - 2].s[i] = st[sp - 2].s[i] + st[sp - 1].s[i]; sp--; break;
+		case 9: for (int i = 0; i < ORC_NBINS; i++) st[sp - 2].s[i] = st[sp - 2].s[i] * st[sp - 1].s[i]; sp--; break;
+		case 10: st[sp - 2].v = vadd(st[sp - 2].v, st[sp - 1].v); sp--; break;
+		case 11: for (int i = 0; i < 3; i++) st[sp - 2].v.e[i] *= st[sp - 1].v.e[i]; sp--; break;
+		default: break;
+		}
+	}
+	memcpy(out, st[0].s, sizeof(double) * ORC_NBINS);
+}
+
+/* the material of a hit; when the object's slot a is a per-hit graph, a copy with that slot evaluated at rec->vt (the copies rotate
+ * through a small thread-local ring: at most a handful of them are alive at once inside one integrator step) */
+static const orc_material *mat_at(const orc_scene *s, uint32_t object, v3 vt)
+{
+	static _Thread_local orc_material ring[16];
+	static _Thread_local int next = 0;
+	if (!s->prog_len || s->prog_len[object] == 0) return &s->mats[object];
+	orc_material *m = &ring[next];
+	next = (next + 1) & 15;
+	*m = s->mats[object];
+	graph_eval(s, s->prog_begin[object], s->prog_len[object], vt, m->a);
+	return m;
+}
+static inline const orc_material *rec_mat(const orc_scene *s, const hitrec *rec) { return mat_at(s, s->object_id[rec->poly], rec->vt); }
 
 #define WORLD_MODE ORC_MODE_BVH_REFERENCE
 
@@ -1367,11 +1488,13 @@ static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t
 	size_t K = 0;
 	double alpha = 1.0, alpha_ = 1.0;
 	int last_eye_ray_hit = 0; /* what world->Hit(_ray, ...) at :558 returns: _ray is still the eye subpath's last ray there */
+	v3 last_eye_vt = V(0, 0, 0);
 	for (;;) {
 		hitrec rec;
 		st->closest_rays++;
 		last_eye_ray_hit = world_hit(s, WORLD_MODE, o, d, 0.001, DBL_MAX, &rec);
 		if (!last_eye_ray_hit) break;
+		last_eye_vt = rec.vt;
 		const orc_material *m = rec_mat(s, &rec);
 		if (m->light_flag) break;
 		alpha *= alpha_;
@@ -1409,7 +1532,7 @@ static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t
 	double light_dir_pdf_projected = light_dir_pdf_solidangle / vdot(light_normal, dir);
 	double light_value = 0.0;
 	st->closest_rays++; /* :558 traces _ray (the eye subpath's last ray), not shadow_ray: same result as that ray's own trace */
-	if (last_eye_ray_hit) light_value = mat_emitted(&s->mats[s->object_id[lf]], b);
+	if (last_eye_ray_hit) light_value = mat_emitted(mat_at(s, s->object_id[lf], last_eye_vt), b); /* Emitted(shadow_ray, sampled_light_rec, sampled_light_rec.vt) */
 	hitrec lrec[ORC_BDPT_MAX];
 	v3 lray_d[ORC_BDPT_MAX];
 	double betas[ORC_BDPT_MAX];

@@ -133,6 +133,12 @@ typedef struct orc_material {
 /* BiliteralFilter::FilterImage (filter.cpp:13-51); pinned by the compiled reference (oracle/_ref/libref_filter.so) */
 void orc_bilateral(const double *img, int img_width, int img_height, int window, double sigma_d, double sigma_r, double *result);
 int orc_scene_set_materials(orc_scene *s, const orc_material *per_object, uint32_t n_objects); /* renderer.cpp:24-44 */
+/* per-hit material graphs (the Compute() chains of materialnode.cpp that read the hit's texture coordinate), as postfix programs for
+ * slot a (albedo / color) of some objects; see graph_eval in rt_oracle.c for the ops; parity unpinned */
+int orc_scene_set_material_graphs(orc_scene *s, const uint32_t *programs, uint32_t n_programs, const uint32_t *code, uint32_t n_code,
+                                  const double *spectra, uint32_t n_spectra, const double *vectors, uint32_t n_vectors,
+                                  const double *scalars, uint32_t n_scalars, const uint8_t *const *tex, const int *tex_w,
+                                  const int *tex_h, const int *tex_bpp, uint32_t n_textures);
 /* environment texture of NaivePathTracing (renderer.cpp:175-193; globals of scene.h:20-22); parity unpinned */
 int orc_scene_set_environment(orc_scene *s, const uint8_t *tex, int w, int h, int bpp, double brightness);
 int orc_sphere_hit(const double o[3], const double d[3], double t_min, double t_max, double *t); /* object.cpp:43-75, dome of renderer.cpp:169-171 */

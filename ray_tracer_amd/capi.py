@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libm
 
 # every symbol include/mi355rt.h declares
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_environment", "rt_upload_materials", "rt_set_camera", "rt_clear",
+    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_environment", "rt_upload_materials", "rt_upload_material_graphs", "rt_set_camera", "rt_clear",
     "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
     "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
     "rt_get_stats", "rt_get_bvh2", "rt_filter_bilateral", "rt_filter_bilateral_device", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
@@ -37,6 +37,16 @@ class Mesh(C.Structure):
 
 class Material(C.Structure):
     _fields_ = [("type", C.c_int32), ("light_flag", C.c_int32), ("a", C.c_double * NBINS), ("b", C.c_double * NBINS)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("bpp", C.c_int32)]
+
+
+class MaterialGraphs(C.Structure):
+    _fields_ = [("programs", C.c_void_p), ("n_programs", C.c_uint32), ("code", C.c_void_p), ("n_code", C.c_uint32),
+                ("spectra", C.c_void_p), ("n_spectra", C.c_uint32), ("vectors", C.c_void_p), ("n_vectors", C.c_uint32),
+                ("scalars", C.c_void_p), ("n_scalars", C.c_uint32), ("textures", C.c_void_p), ("n_textures", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -89,6 +99,7 @@ def load():
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_upload_mesh.argtypes = [vp, C.POINTER(Mesh)]
     lib.rt_set_builder.argtypes = [vp, C.c_int]
+    lib.rt_upload_material_graphs.argtypes = [vp, vp]
     lib.rt_filter_bilateral.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]
     lib.rt_filter_bilateral_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]
     lib.rt_set_environment.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
@@ -190,6 +201,27 @@ class Context:
                 arr[i].a[k] = float(m["a"][k])
                 arr[i].b[k] = float(m["b"][k])
         self._check(self.lib.rt_upload_materials(self.h, arr, len(materials)))
+        self.upload_material_graphs(materials)
+
+    def upload_material_graphs(self, materials):
+        """attaches the per-hit programs of the records that carry a "graph" (NodeMaterial.record()); none: nothing to do"""
+        from . import scene_io
+        g = scene_io.compile_material_graphs(materials)
+        if g is None:
+            return
+        tex = [np.ascontiguousarray(t, dtype=np.uint8) for t in g["textures"]]
+        tarr = (Texture * max(len(tex), 1))()
+        for i, t in enumerate(tex):
+            tarr[i].texels = t.ctypes.data
+            tarr[i].width, tarr[i].height, tarr[i].bpp = t.shape[1], t.shape[0], t.shape[2]
+        progs = np.ascontiguousarray(g["programs"], dtype=np.uint32)
+        code = np.ascontiguousarray(g["code"], dtype=np.uint32)
+        spectra = np.ascontiguousarray(g["spectra"], dtype=np.float64)
+        vectors = np.ascontiguousarray(g["vectors"], dtype=np.float64)
+        scalars = np.ascontiguousarray(g["scalars"], dtype=np.float64)
+        mg = MaterialGraphs(_ptr(progs), len(progs), _ptr(code), len(code), _ptr(spectra), len(spectra), _ptr(vectors), len(vectors),
+                            _ptr(scalars), len(scalars), C.cast(tarr, C.c_void_p), len(tex))
+        self._check(self.lib.rt_upload_material_graphs(self.h, C.byref(mg)))
 
     def set_camera(self, cam):
         c = Camera()

@@ -238,6 +238,57 @@ int rt_upload_materials(rt_context *ctx, const rt_material *per_object, uint32_t
 	return RT_OK;
 }
 
+int rt_upload_material_graphs(rt_context *ctx, const rt_material_graphs *g)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	if (!ctx->has_materials) return set_err(ctx, RT_ERR_INVALID, "rt_upload_material_graphs: upload the material records first");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (g && g->n_programs) {
+		for (uint32_t t = 0; t < g->n_textures; t++)
+			if (!g->textures[t].texels || g->textures[t].width <= 0 || g->textures[t].height <= 0 || g->textures[t].bpp < 3)
+				return set_err(ctx, RT_ERR_INVALID, "rt_upload_material_graphs: a texture needs texels, width, height > 0 and at least 3 bytes per texel");
+		for (uint32_t i = 0; i < g->n_programs; i++) {
+			const rt_graph_program &p = g->programs[i];
+			if (p.object >= ctx->host.n_objects || p.code_len == 0 || (uint64_t)p.code_begin + p.code_len > g->n_code)
+				return set_err(ctx, RT_ERR_INVALID, "rt_upload_material_graphs: program outside the object or code table");
+			const int type = ctx->materials[p.object].type;
+			if (type != RT_MAT_LAMBERTIAN && type != RT_MAT_DIFFUSE_LIGHT && type != RT_MAT_COLORED_METAL)
+				return set_err(ctx, RT_ERR_INVALID, "rt_upload_material_graphs: only Lambertian, DiffuseLight and ColoredMetal have a slot fed by a graph");
+			// type-check the program on an abstract stack: 'S' spectrum, 'V' vector
+			char st[4];
+			int sp = 0;
+			auto bad = [&](const char *why) { return set_err(ctx, RT_ERR_INVALID, std::string("rt_upload_material_graphs: ") + why); };
+			for (uint32_t pc = p.code_begin; pc < p.code_begin + p.code_len; pc++) {
+				const uint32_t op = g->code[2 * pc], arg = g->code[2 * pc + 1];
+				char push = 0;
+				switch (op) {
+				case 0: if (arg >= g->n_spectra) return bad("spectrum index out of range"); push = 'S'; break;
+				case 1: if (arg >= g->n_vectors) return bad("vector index out of range"); push = 'V'; break;
+				case 2: push = 'V'; break;
+				case 3: push = 'S'; break;
+				case 4: push = 'V'; break;
+				case 5: if (arg >= g->n_textures) return bad("texture index out of range");
+					if (sp < 1 || st[sp - 1] != 'V') return bad("IMAGE needs a vector"); break;
+				case 6: if (arg >= g->n_scalars) return bad("scalar index out of range");
+					if (sp < 1 || st[sp - 1] != 'V') return bad("CHECKER needs a vector"); break;
+				case 7: if (sp < 1 || st[sp - 1] != 'V') return bad("RGB2SPEC needs a vector"); st[sp - 1] = 'S'; break;
+				case 8: case 9: if (sp < 2 || st[sp - 1] != 'S' || st[sp - 2] != 'S') return bad("spectrum arithmetic needs two spectra"); sp--; break;
+				case 10: case 11: if (sp < 2 || st[sp - 1] != 'V' || st[sp - 2] != 'V') return bad("vector arithmetic needs two vectors"); sp--; break;
+				default: return bad("unknown op");
+				}
+				if (push) {
+					if (sp == 4) return bad("program needs more than four stack entries");
+					st[sp++] = push;
+				}
+			}
+			if (sp != 1 || st[0] != 'S') return bad("a program must leave exactly one spectrum");
+		}
+	}
+	std::string err;
+	if (render_upload_material_graphs(ctx->render, g, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
+	return RT_OK;
+}
+
 int rt_set_environment(rt_context *ctx, const uint8_t *texels, int width, int height, int bpp, double brightness)
 {
 	if (!ctx) return RT_ERR_INVALID;

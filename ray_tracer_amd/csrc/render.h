@@ -89,6 +89,8 @@ struct RenderState {
 // tri_leaf: fan triangle -> leaf-order index; d_tri_face / d_face_object: the geometry's device tables
 hipError_t render_upload_scene(RenderState &rs, const HostScene &host, const std::vector<uint32_t> &tri_leaf,
                                const uint32_t *d_tri_face, const uint32_t *d_face_object, hipStream_t stream, std::string &err);
+// per-hit material programs for slot a of some objects (validated by the caller); nullptr or no programs removes them
+hipError_t render_upload_material_graphs(RenderState &rs, const rt_material_graphs *g, hipStream_t stream, std::string &err);
 // environment texture of the naive integrator (renderer.cpp:175-193); texels == nullptr removes it
 hipError_t render_set_environment(RenderState &rs, const uint8_t *texels, int width, int height, int bpp, double brightness, hipStream_t stream, std::string &err);
 hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const std::vector<rt_material> &mats,

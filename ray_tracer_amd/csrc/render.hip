@@ -29,6 +29,7 @@ constexpr float kPi = 3.14159265358979323846f;
 struct DevMaterial {
 	int type, light_flag;
 	float a[RT_NBINS], b[RT_NBINS];
+	uint32_t prog_begin, prog_len; // slot a (albedo / color) as a per-hit program when prog_len != 0
 };
 
 // One wavelength band of the pass loop (renderer.cpp:85-88) with everything that depends on it
@@ -53,6 +54,11 @@ struct DeviceShade {
 	const uint32_t *light_faces;
 	const DevBand *bands;
 	uint32_t n_lights, n_bands;
+	const float *tri_uv;            // 9 floats per fan triangle: vt of its three corners (null: the mesh has none)
+	const uint2 *g_code;            // per-hit material programs: (op, arg) pairs
+	const float *g_spectra, *g_vectors, *g_scalars;
+	const int4 *g_tex;              // per texture: byte offset into g_texels, width, height, bytes per texel
+	const uint8_t *g_texels;
 	const uint8_t *env;             // environment texture of the naive integrator (null: none), env_h rows of env_w texels
 	int env_w, env_h, env_bpp;
 	float env_brightness;
@@ -92,6 +98,12 @@ struct Impl {
 	uint32_t *light_faces = nullptr;
 	DevBand *bands = nullptr;
 	uint32_t n_lights = 0, n_bands = 0;
+	float *tri_uv = nullptr;
+	uint2 *g_code = nullptr;
+	float *g_spectra = nullptr, *g_vectors = nullptr, *g_scalars = nullptr;
+	int4 *g_tex = nullptr;
+	uint8_t *g_texels = nullptr;
+	std::vector<DevMaterial> host_materials; // kept so that programs can be attached after the records went up
 	uint8_t *env = nullptr;
 	int env_w = 0, env_h = 0, env_bpp = 0;
 	float env_brightness = 0.0f;
@@ -181,17 +193,77 @@ __device__ __forceinline__ void film_add(float *film, uint32_t pixel, const DevB
 	for (int i = bd.min_i; i <= bd.max_i; i++) atomicAdd(&film[(size_t)pixel * RT_NBINS + i], value);
 }
 
-__device__ __forceinline__ float mat_emitted(const DevMaterial &m, const DevBand &bd) // materialnode.cpp:215-218,739-749
+// ---- per-hit material graphs: the Compute() chains of materialnode.cpp that read the hit's texture coordinate, compiled by the
+// host to a postfix program for slot a (albedo / color).  Values are vectors, spectra live in .x (one bin is evaluated at a time).
+// The value stack is four registers deep (rt_upload_material_graphs refuses deeper programs).
+enum { OP_SPEC = 0, OP_VEC, OP_UV, OP_ZERO_S, OP_ZERO_V, OP_IMAGE, OP_CHECKER, OP_RGB2SPEC, OP_ADD_S, OP_MUL_S, OP_ADD_V, OP_MUL_V };
+
+__device__ float eval_graph(const DeviceShade &sh, uint32_t begin, uint32_t len, f3 uv, int bin)
 {
-	return m.type == RT_MAT_DIFFUSE_LIGHT ? spectrum_integrate(m.a, bd) : 0.0f;
+	f3 s0 = F3(0, 0, 0), s1 = s0, s2 = s0, s3 = s0; // s0 is the top
+	for (uint32_t pc = begin; pc < begin + len; pc++) {
+		const uint2 c = sh.g_code[pc];
+		f3 v = F3(0, 0, 0);
+		int delta = 0; // +1 push v, -1 replace the two top values by v, 0 replace the top by v
+		switch (c.x) {
+		case OP_SPEC: v = F3(sh.g_spectra[(size_t)c.y * RT_NBINS + bin], 0, 0); delta = 1; break;
+		case OP_VEC: v = ld3(sh.g_vectors + 3 * (size_t)c.y); delta = 1; break;
+		case OP_UV: v = uv; delta = 1; break; // UVNode, materialnode.cpp:893-896
+		case OP_ZERO_S:
+		case OP_ZERO_V: delta = 1; break;
+		case OP_IMAGE: { // ImageTextureNode::Compute, :1007-1018; an address outside the texture (undefined in the reference) reads its nearest end
+			const int4 t = sh.g_tex[c.y];
+			const int x = (int)((double)t.y * (double)s0.x), y = (int)((double)t.z * (1.0 - (double)s0.y));
+			long idx = (long)x + (long)y * t.y;
+			idx = idx < 0 ? 0 : (idx > (long)t.y * t.z - 1 ? (long)t.y * t.z - 1 : idx);
+			const uint8_t *px = sh.g_texels + t.x + (long)t.w * idx;
+			v = F3((float)((double)px[0] / 255.0), (float)((double)px[1] / 255.0), (float)((double)px[2] / 255.0));
+			break;
+		}
+		case OP_CHECKER: { // CheckerboardNode::Compute, :1055-1062
+			const double size = (double)sh.g_scalars[c.y], u = (double)s0.x, w = (double)s0.y;
+			const int x = (int)((u - fmod(u, size)) / size), y = (int)((w - fmod(w, size)) / size);
+			v = (x % 2 == y % 2) ? F3(1, 1, 1) : F3(0, 0, 0);
+			break;
+		}
+		case OP_RGB2SPEC: v = F3(bin < RT_NBINS / 3 ? s0.z : (bin < 2 * RT_NBINS / 3 ? s0.y : s0.x), 0, 0); break; // spectrum.cpp:219-232
+		case OP_ADD_S: v = F3(s1.x + s0.x, 0, 0); delta = -1; break;
+		case OP_MUL_S: v = F3(s1.x * s0.x, 0, 0); delta = -1; break;
+		case OP_ADD_V: v = s1 + s0; delta = -1; break;
+		case OP_MUL_V: v = F3(s1.x * s0.x, s1.y * s0.y, s1.z * s0.z); delta = -1; break;
+		default: break;
+		}
+		if (delta > 0) { s3 = s2; s2 = s1; s1 = s0; }
+		else if (delta < 0) { s1 = s2; s2 = s3; }
+		s0 = v;
+	}
+	return s0.x;
+}
+
+// slot a of the material at a hit with texture coordinate uv, read at one bin
+__device__ __forceinline__ float slot_a(const DeviceShade &sh, const DevMaterial &m, f3 uv, int bin)
+{
+	return m.prog_len ? eval_graph(sh, m.prog_begin, m.prog_len, uv, bin) : m.a[bin];
+}
+
+__device__ __forceinline__ float mat_emitted(const DeviceShade &sh, const DevMaterial &m, f3 uv, const DevBand &bd) // materialnode.cpp:215-218,739-749
+{
+	if (m.type != RT_MAT_DIFFUSE_LIGHT) return 0.0f;
+	if (!m.prog_len) return spectrum_integrate(m.a, bd);
+	float sum = 0.0f; // Spectrum::integrate (spectrum.cpp:126-146) over the spectrum the graph yields at this hit
+	if (bd.flags & 1) sum += eval_graph(sh, m.prog_begin, m.prog_len, uv, bd.min_i - 1) * bd.mod_min;
+	if (bd.flags & 2) sum += eval_graph(sh, m.prog_begin, m.prog_len, uv, bd.max_i + 1) * bd.mod_max;
+	for (int i = bd.min_i; i <= bd.max_i; i++) sum += eval_graph(sh, m.prog_begin, m.prog_len, uv, i) * 10.0f;
+	return sum;
 }
 
 __device__ __forceinline__ bool mirror_pair(f3 vi, f3 vo) { return -vi.x == vo.x && -vi.y == vo.y && vi.z == vo.z; }
 
-__device__ __forceinline__ float mat_bsdf(const DevMaterial &m, f3 vi, f3 vo, int bin)
+// a: slot a of the material at this hit and bin (slot_a)
+__device__ __forceinline__ float mat_bsdf(const DevMaterial &m, f3 vi, f3 vo, float a)
 {
 	switch (m.type) {
-	case RT_MAT_LAMBERTIAN: return vi.z < 0.0f ? 0.0f : m.a[bin] / kPi;                       // materialnode.cpp:278-288
+	case RT_MAT_LAMBERTIAN: return vi.z < 0.0f ? 0.0f : a / kPi;                               // materialnode.cpp:278-288
 	case RT_MAT_CONDUCTOR:
 	case RT_MAT_COLORED_METAL: return mirror_pair(vi, vo) ? __int_as_float(0x7f800000) : 0.0f; // :503-508, :585-590
 	default: return 0.0f;
@@ -238,7 +310,7 @@ __device__ __forceinline__ float cfresnel(float cos_theta, float nre, float nim)
 
 // NodeMaterial::SampleBSDF for ImportanceType rays (materialnode.cpp:1758-1766 and the node bodies)
 // light_type: RayType LightType (the light subpath of NaiveBDPT, renderer.cpp:589); only the dielectric's refraction tells them apart
-__device__ __forceinline__ bool mat_sample(const DevMaterial &m, f3 normal, const Onb &uvw, f3 vo, int bin, uint64_t &rng,
+__device__ __forceinline__ bool mat_sample(const DevMaterial &m, f3 normal, const Onb &uvw, f3 vo, int bin, float a, uint64_t &rng,
                                            f3 &vi, float &ratio, float &pdfval, bool light_type = false)
 {
 	switch (m.type) {
@@ -251,7 +323,7 @@ __device__ __forceinline__ bool mat_sample(const DevMaterial &m, f3 normal, cons
 		float cos_theta = dot(gen, pb.w);
 		pdfval = cos_theta >= 0.0f ? cos_theta / kPi : 0.0f;
 		vi = w2l(uvw, gen);
-		float bsdf = mat_bsdf(m, vi, vo, bin);
+		float bsdf = mat_bsdf(m, vi, vo, a);
 		ratio = bsdf / pdfval;
 		return true;
 	}
@@ -288,7 +360,7 @@ __device__ __forceinline__ bool mat_sample(const DevMaterial &m, f3 normal, cons
 	case RT_MAT_COLORED_METAL: // :564-584
 		vi = F3(-vo.x, -vo.y, vo.z);
 		pdfval = __int_as_float(0x7f800000);
-		ratio = m.a[bin] / fabsf(vo.z);
+		ratio = a / fabsf(vo.z);
 		return true;
 	default: return false; // base class, :203-206
 	}
@@ -316,6 +388,16 @@ __device__ __forceinline__ f3 shading_normal(const TriShade &t, f3 p)
 {
 	f3 r0 = cross(t.v1 - t.v0, p - t.v1), r1 = cross(t.v2 - t.v1, p - t.v2), r2 = cross(t.v0 - t.v2, p - t.v0);
 	f3 s = len(r1) * t.n0 + len(r2) * t.n1 + len(r0) * t.n2;
+	return F3(s.x / t.area2, s.y / t.area2, s.z / t.area2);
+}
+
+// rec.vt of HitTriangle (object.cpp:258): the same sub-triangle weights as the normal; zero when the mesh has no vt
+__device__ __forceinline__ f3 hit_uv(const DeviceShade &sh, uint32_t tri_id, const TriShade &t, f3 p)
+{
+	if (!sh.tri_uv) return F3(0, 0, 0);
+	const float *q = sh.tri_uv + 9 * (size_t)tri_id;
+	const f3 r0 = cross(t.v1 - t.v0, p - t.v1), r1 = cross(t.v2 - t.v1, p - t.v2), r2 = cross(t.v0 - t.v2, p - t.v0);
+	const f3 s = len(r1) * ld3(q) + len(r2) * ld3(q + 3) + len(r0) * ld3(q + 6);
 	return F3(s.x / t.area2, s.y / t.area2, s.z / t.area2);
 }
 
@@ -472,13 +554,15 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DeviceShade sh, const uin
 			const TriShade tri = load_tri(sh.tri_shade, h.tri);
 			const f3 nrm = shading_normal(tri, p);
 			const DevMaterial &m = sh.materials[h.object];
+			const f3 uv = m.prog_len ? hit_uv(sh, h.tri, tri, p) : F3(0, 0, 0); // rec.vt, only read by per-hit material graphs
+			const float a_bin = slot_a(sh, m, uv, bd.get_bin);
 			const float tmin = r.tmin;
 			bool alive = true;
 			if (ALG == RT_ALG_NAIVE) {
-				film_add(film, st.pixel, bd, st.beta * mat_emitted(m, bd) * st.weight); // renderer.cpp:197
+				film_add(film, st.pixel, bd, st.beta * mat_emitted(sh, m, uv, bd) * st.weight); // renderer.cpp:197
 			} else if (m.light_flag) { // renderer.cpp:242-251 / 346-355
 				if (bounce != 0) alive = false;
-				else film_add(film, st.pixel, bd, mat_emitted(m, bd) * st.weight);
+				else film_add(film, st.pixel, bd, mat_emitted(sh, m, uv, bd) * st.weight);
 			}
 			if (alive) {
 				const Onb uvw = onb_from_w(nrm);
@@ -501,7 +585,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DeviceShade sh, const uin
 					const float dist = len(to_l);
 					const f3 sd = F3(to_l.x / dist, to_l.y / dist, to_l.z / dist);
 					const f3 vi = w2l(uvw, sd);
-					const float bsdf = mat_bsdf(m, vi, vo, bd.get_bin);
+					const float bsdf = mat_bsdf(m, vi, vo, a_bin);
 					const float lpa = 1.0f / area / (float)sh.n_lights;
 					cr0.ox = p.x; cr0.oy = p.y; cr0.oz = p.z; cr0.tmin = tmin;
 					cr0.dx = sd.x; cr0.dy = sd.y; cr0.dz = sd.z;
@@ -511,7 +595,8 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DeviceShade sh, const uin
 					if (ALG == RT_ALG_NEE) { // renderer.cpp:258-286
 						cr0.tmax = dist - 0.0001f;
 						const float G = fabsf(dot(sd, ltri.fn) * dot(sd, nrm) / dot(to_l, to_l));
-						const float light = mat_emitted(sh.materials[sh.face_object[lf]], bd);
+						const DevMaterial &lm = sh.materials[sh.face_object[lf]]; // Emitted(shadow_ray, light_rec, light_rec.vt), :278-282
+						const float light = mat_emitted(sh, lm, lm.prog_len ? hit_uv(sh, lt, ltri, pl) : F3(0, 0, 0), bd);
 						c0.c0 = bsdf * st.beta * light * G / lpa * st.weight;
 						c0.c1 = dist;
 						c0.band_kind = band | (2u << 16);
@@ -526,7 +611,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DeviceShade sh, const uin
 						// BSDF-sampled direct light, renderer.cpp:404-433
 						f3 gvi;
 						float ratio, pdfv;
-						if (mat_sample(m, nrm, uvw, vo, bd.get_bin, st.rng, gvi, ratio, pdfv)) {
+						if (mat_sample(m, nrm, uvw, vo, bd.get_bin, a_bin, st.rng, gvi, ratio, pdfv)) {
 							const f3 sdir = l2w(uvw, gvi); // not normalised, :413
 							cr1.ox = p.x; cr1.oy = p.y; cr1.oz = p.z; cr1.tmin = 0.001f;
 							cr1.dx = sdir.x; cr1.dy = sdir.y; cr1.dz = sdir.z; cr1.tmax = __int_as_float(0x7f800000);
@@ -541,7 +626,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DeviceShade sh, const uin
 				// continuation sample (renderer.cpp:199-208 / 290-300 / 440-450)
 				f3 gvi;
 				float ratio, pdfv;
-				const bool respawn = mat_sample(m, nrm, uvw, vo, bd.get_bin, st.rng, gvi, ratio, pdfv);
+				const bool respawn = mat_sample(m, nrm, uvw, vo, bd.get_bin, a_bin, st.rng, gvi, ratio, pdfv);
 				if (ALG == RT_ALG_NAIVE) {
 					if (respawn) {
 						st.beta *= ratio * fabsf(gvi.z);
@@ -637,7 +722,8 @@ __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh
 	const f3 dir = unit(v);
 	const f3 nrm = F3(c.nx, c.ny, c.nz);
 	const float G = fabsf(dot(dir, ln) * dot(dir, nrm) / dot(v, v));
-	const float light = mat_emitted(sh.materials[h.object], bd);
+	const DevMaterial &lm = sh.materials[h.object];
+	const float light = mat_emitted(sh, lm, lm.prog_len ? hit_uv(sh, h.tri, tri, pl) : F3(0, 0, 0), bd);
 	const float lpa = 1.0f / sh.face_area[c.sel_face] / (float)sh.n_lights;
 	float add;
 	if (kind == 0) add = power_heuristic2(lpa, c.c1 * G) * (c.c0 * G) * light;      // renderer.cpp:390-399
@@ -733,6 +819,13 @@ DeviceShade make_shade(const Impl &im)
 	sh.bands = im.bands;
 	sh.n_lights = im.n_lights;
 	sh.n_bands = im.n_bands;
+	sh.tri_uv = im.tri_uv;
+	sh.g_code = im.g_code;
+	sh.g_spectra = im.g_spectra;
+	sh.g_vectors = im.g_vectors;
+	sh.g_scalars = im.g_scalars;
+	sh.g_tex = im.g_tex;
+	sh.g_texels = im.g_texels;
 	sh.env = im.env;
 	sh.env_w = im.env_w;
 	sh.env_h = im.env_h;
@@ -791,6 +884,21 @@ hipError_t render_upload_scene(RenderState &rs, const HostScene &host, const std
 	for (uint64_t f = 0; f < host.n_faces; f++) fa[f] = (float)host.polygon_area[f];
 	for (uint64_t t = 0; t < host.n_tris; t++) tc[t] = (float)host.tri_cum[t];
 	HIP_TRY(upload(im.tri_shade, ts, stream));
+	// texture coordinates of the fan triangles' corners, only when the mesh has any (read by per-hit material graphs)
+	bool any_vt = false;
+	for (double x : host.pvt) if (x != 0.0) { any_vt = true; break; }
+	if (im.tri_uv) { (void)hipFree(im.tri_uv); im.tri_uv = nullptr; }
+	if (any_vt) {
+		std::vector<float> uv(9 * host.n_tris);
+		for (uint64_t t = 0; t < host.n_tris; t++) {
+			const uint32_t f = host.tri_face[t];
+			const uint64_t b = host.face_begin[f], k = t - host.tri_begin[f];
+			const uint64_t c[3] = {b, b + k + 1, b + k + 2};
+			for (int i = 0; i < 3; i++)
+				for (int a = 0; a < 3; a++) uv[9 * t + 3 * i + a] = (float)host.pvt[3 * c[i] + a];
+		}
+		HIP_TRY(upload(im.tri_uv, uv, stream));
+	}
 	HIP_TRY(upload(im.face_tri_begin, ftb, stream));
 	HIP_TRY(upload(im.face_area, fa, stream));
 	HIP_TRY(upload(im.tri_cum, tc, stream));
@@ -798,6 +906,51 @@ hipError_t render_upload_scene(RenderState &rs, const HostScene &host, const std
 	im.tri_face = d_tri_face;
 	im.face_object = d_face_object;
 	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_cie), h_cie, sizeof(h_cie)));
+	return hipSuccess;
+}
+
+static void free_graphs(Impl &im)
+{
+	void *ptrs[] = {im.g_code, im.g_spectra, im.g_vectors, im.g_scalars, im.g_tex, im.g_texels};
+	for (void *p : ptrs) if (p) (void)hipFree(p);
+	im.g_code = nullptr; im.g_spectra = im.g_vectors = im.g_scalars = nullptr; im.g_tex = nullptr; im.g_texels = nullptr;
+}
+
+// programs were validated by the caller (api.cpp): ops, table indices, stack depth and result type
+hipError_t render_upload_material_graphs(RenderState &rs, const rt_material_graphs *g, hipStream_t stream, std::string &err)
+{
+	Impl &im = *impl_of(rs);
+	HIP_TRY(hipStreamSynchronize(stream));
+	free_graphs(im);
+	std::vector<DevMaterial> dm = im.host_materials;
+	for (auto &m : dm) m.prog_begin = m.prog_len = 0;
+	if (g && g->n_programs) {
+		for (uint32_t i = 0; i < g->n_programs; i++) {
+			dm[g->programs[i].object].prog_begin = g->programs[i].code_begin;
+			dm[g->programs[i].object].prog_len = g->programs[i].code_len;
+		}
+		std::vector<uint2> code(g->n_code);
+		for (uint32_t i = 0; i < g->n_code; i++) code[i] = make_uint2(g->code[2 * i], g->code[2 * i + 1]);
+		std::vector<float> spectra((size_t)g->n_spectra * RT_NBINS), vectors((size_t)g->n_vectors * 3), scalars(g->n_scalars);
+		for (size_t i = 0; i < spectra.size(); i++) spectra[i] = (float)g->spectra[i];
+		for (size_t i = 0; i < vectors.size(); i++) vectors[i] = (float)g->vectors[i];
+		for (size_t i = 0; i < scalars.size(); i++) scalars[i] = (float)g->scalars[i];
+		std::vector<int4> tex(g->n_textures);
+		std::vector<uint8_t> texels;
+		for (uint32_t i = 0; i < g->n_textures; i++) {
+			const rt_texture &t = g->textures[i];
+			tex[i] = make_int4((int)texels.size(), t.width, t.height, t.bpp);
+			texels.insert(texels.end(), t.texels, t.texels + (size_t)t.width * t.height * t.bpp);
+		}
+		HIP_TRY(upload(im.g_code, code, stream));
+		HIP_TRY(upload(im.g_spectra, spectra, stream));
+		HIP_TRY(upload(im.g_vectors, vectors, stream));
+		HIP_TRY(upload(im.g_scalars, scalars, stream));
+		HIP_TRY(upload(im.g_tex, tex, stream));
+		HIP_TRY(upload(im.g_texels, texels, stream));
+	}
+	HIP_TRY(upload(im.materials, dm, stream));
+	im.host_materials = dm;
 	return hipSuccess;
 }
 
@@ -811,8 +964,11 @@ hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const
 		dm[i].type = mats[i].type;
 		dm[i].light_flag = mats[i].light_flag;
 		for (int k = 0; k < RT_NBINS; k++) { dm[i].a[k] = (float)mats[i].a[k]; dm[i].b[k] = (float)mats[i].b[k]; }
+		dm[i].prog_begin = dm[i].prog_len = 0;
 	}
 	HIP_TRY(upload(im.materials, dm, stream));
+	im.host_materials = dm;
+	free_graphs(im); // new records: programs have to be attached again
 	HIP_TRY(upload(im.light_faces, light_faces, stream));
 	im.n_lights = (uint32_t)light_faces.size();
 	return hipSuccess;
@@ -1220,6 +1376,8 @@ void render_free(RenderState &rs)
 		if (im.light_faces) (void)hipFree(im.light_faces);
 		if (im.bands) (void)hipFree(im.bands);
 		if (im.env) (void)hipFree(im.env);
+		if (im.tri_uv) (void)hipFree(im.tri_uv);
+		free_graphs(im);
 		free_bdpt(im);
 		if (im.counters) {
 			(void)hipFree(im.counters);

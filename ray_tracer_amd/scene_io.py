@@ -459,8 +459,8 @@ def write_ply(path, vertices, faces, normals=None, binary=False):
 # material node graphs (materialnode.cpp)
 # ----------------------------------------------------------------------------------------------
 class UnsupportedMaterialGraph(ValueError):
-    """The graph depends on the hit's texture coordinate (or uses a node the reference leaves
-    undefined); only graphs that fold to constant spectra run on the device."""
+    """The graph uses a node that is not evaluated on the device (noise, rotation, component access) or one the
+    reference leaves undefined (GGX)."""
 
 
 def rgb_to_spectrum(rgb):  # spectrum.cpp:219-232
@@ -477,7 +477,8 @@ class NodeMaterial:
     `record()` returns the flat dict rt_upload_materials takes."""
     OUTPUT_I = 1  # nodes 0/1 are always UV/Output (materialnode.h:449-450)
 
-    def __init__(self, j):
+    def __init__(self, j, textures=None):
+        self.textures = dict(textures or {})  # path -> uint8 [h, w, bpp] for ImageTexture nodes
         self.name = j.get("name", "untitled material")
         self.light_flag = bool(j.get("light_flag", False))
         self.nodes = j["nodes"]
@@ -543,6 +544,105 @@ class NodeMaterial:
             raise UnsupportedMaterialGraph("node %s of material %s needs per-hit evaluation" % (t, self.name))
         return np.zeros(3)
 
+    # ---- per-hit graphs: the same walks, but a sub-graph that reads the hit's texture coordinate becomes an expression
+    # ("S", spectrum) | ("V", vec3) constants; ("UV",); ("IMG", texels, uv); ("CHK", size, uv); ("R2S", vec);
+    # ("ADDS" | "MULS", a, b) on spectra; ("ADDV" | "MULV", a, b) on vectors
+    def _texture(self, path):
+        """texels of an ImageTexture node as uint8 [h, w, bpp], or None when there is no readable file (the reference then leaves
+        its output untouched, materialnode.cpp:1003-1004).  The reference decodes with stb_image; here: a dict handed to the
+        constructor, .npy files and binary PPM (P6)."""
+        if path in self.textures:
+            return np.ascontiguousarray(self.textures[path], dtype=np.uint8)
+        if not path or not os.path.exists(path):
+            return None
+        if path.endswith(".npy"):
+            return np.ascontiguousarray(np.load(path), dtype=np.uint8)
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:2] != b"P6":
+            raise UnsupportedMaterialGraph("texture %s: only .npy and binary PPM files can be decoded here" % path)
+        tok, pos = [], 2
+        while len(tok) < 3:
+            while data[pos:pos + 1].isspace():
+                pos += 1
+            if data[pos:pos + 1] == b"#":
+                pos = data.index(b"\n", pos) + 1
+                continue
+            end = pos
+            while not data[end:end + 1].isspace():
+                end += 1
+            tok.append(int(data[pos:end]))
+            pos = end
+        w, h, _ = tok
+        return np.frombuffer(data, dtype=np.uint8, count=w * h * 3, offset=pos + 1).reshape(h, w, 3).copy()
+
+    def _vec_expr(self, node_i, depth=0):
+        if depth > 64:
+            raise UnsupportedMaterialGraph("cyclic material graph in %s" % self.name)
+        node = self.nodes[node_i]
+        t = node["type"]
+        zero = ("V", np.zeros(3))
+        if t == "RGBColor":  # :931-936
+            return ("V", np.asarray(node["col"], dtype=np.float64))
+        if t == "UV":  # :893-896
+            return ("UV",)
+        if t == "ImageTexture":  # :1001-1018
+            tex = self._texture(node.get("path", ""))
+            p = self._parent(node_i, "UV")
+            if tex is None or p is None:
+                return zero
+            return ("IMG", tex, self._vec_expr(p, depth + 1))
+        if t == "Checkerboard":  # :1046-1063
+            p = self._parent(node_i, "UV")
+            if p is None:
+                return zero
+            return ("CHK", float(node["size"]), self._vec_expr(p, depth + 1))
+        if t in ("Addition", "Multiplication"):  # the dvec3 overloads, :1098-1102 and :1195-1198
+            p0, p1 = self._parent(node_i, "In0"), self._parent(node_i, "In1")
+            if p0 is None:
+                return zero
+            a = self._vec_expr(p0, depth + 1)
+            if p1 is None:
+                return a if t == "Addition" else zero
+            b = self._vec_expr(p1, depth + 1)
+            if a[0] == "V" and b[0] == "V":
+                return ("V", a[1] + b[1] if t == "Addition" else a[1] * b[1])
+            return ("ADDV" if t == "Addition" else "MULV", a, b)
+        if t in ("RodriguesRotation", "CombineVec3Component", "ValueNoise", "ValueNoise2D", "AccessVec3Component", "RandomSampling"):
+            raise UnsupportedMaterialGraph("node %s of material %s is not evaluated on the device" % (t, self.name))
+        return zero  # no dvec3 Compute: the base class leaves the caller's vector untouched (:81-83)
+
+    def _spec_expr(self, node_i, depth=0):
+        if depth > 64:
+            raise UnsupportedMaterialGraph("cyclic material graph in %s" % self.name)
+        node = self.nodes[node_i]
+        t = node["type"]
+        zero = ("S", np.zeros(NBINS))
+        if t == "RGBtoSpectrum":  # :949-957
+            p = self._parent(node_i, "RGB")
+            if p is None:
+                return zero
+            v = self._vec_expr(p, depth + 1)
+            return ("S", rgb_to_spectrum(v[1])) if v[0] == "V" else ("R2S", v)
+        if t in ("Addition", "Multiplication"):
+            p0, p1 = self._parent(node_i, "In0"), self._parent(node_i, "In1")
+            if p0 is None:
+                return zero
+            a = self._spec_expr(p0, depth + 1)
+            if p1 is None:
+                return a if t == "Addition" else zero
+            b = self._spec_expr(p1, depth + 1)
+            if a[0] == "S" and b[0] == "S":
+                return ("S", a[1] + b[1] if t == "Addition" else a[1] * b[1])
+            return ("ADDS" if t == "Addition" else "MULS", a, b)
+        return ("S", self._spectrum(node_i, depth))  # every other node: the constant walk
+
+    def _slot_expr(self, node_i, slot, own_key):
+        p = self._parent(node_i, slot)
+        if p is None:
+            return ("S", self._slot_spectrum(node_i, slot, own_key))
+        return self._spec_expr(p)
+
     def _slot_spectrum(self, node_i, slot, own_key):
         p = self._parent(node_i, slot)
         if p is None:
@@ -563,23 +663,74 @@ class NodeMaterial:
         node = self.nodes[b]
         t = node["type"]
         own = lambda key: np.asarray((list(node.get(key, [])) + [0.0] * NBINS)[:NBINS], dtype=np.float64)
+        def slot_a(slot):
+            e = self._slot_expr(b, slot, slot)
+            if e[0] == "S":
+                return {"a": e[1]}
+            return {"a": zero, "graph": e}  # evaluated per hit on the device (rt_upload_material_graphs)
         if t == "Lambertian":
-            rec.update(type=capi.MAT_LAMBERTIAN, a=self._slot_spectrum(b, "albedo", "albedo"))
+            rec.update(type=capi.MAT_LAMBERTIAN, **slot_a("albedo"))
         elif t == "DiffuseLight":
-            rec.update(type=capi.MAT_DIFFUSE_LIGHT, a=self._slot_spectrum(b, "color", "color"))
+            rec.update(type=capi.MAT_DIFFUSE_LIGHT, **slot_a("color"))
         elif t == "Dielectric":
             # "surface_color" never matches the slot named "surface color" (:300,359): always the node's own array
             rec.update(type=capi.MAT_DIELECTRIC, a=own("n"), b=self._slot_spectrum(b, "surface_color", "surface_color"))
         elif t == "Conductor":
             rec.update(type=capi.MAT_CONDUCTOR, a=own("n"), b=own("k"))
         elif t == "ColoredMetal":
-            rec.update(type=capi.MAT_COLORED_METAL, a=self._slot_spectrum(b, "albedo", "albedo"))
+            rec.update(type=capi.MAT_COLORED_METAL, **slot_a("albedo"))
         elif t == "GGXReflection":
             raise UnsupportedMaterialGraph("GGXReflection reads an uninitialised alpha and returns no value from "
                                            "BSDF()/PDF() in the reference (materialnode.cpp:647-695)")
         else:
             raise UnsupportedMaterialGraph("node type %s wired to the BSDF output of %s" % (t, self.name))
         return rec
+
+
+OP_SPEC, OP_VEC, OP_UV, OP_ZERO_S, OP_ZERO_V, OP_IMAGE, OP_CHECKER, OP_RGB2SPEC, OP_ADD_S, OP_MUL_S, OP_ADD_V, OP_MUL_V = range(12)
+
+
+def compile_material_graphs(records):
+    """records (one per object, as NodeMaterial.record() returns them) -> the tables of rt_upload_material_graphs, or None when
+    no record carries a per-hit graph: programs [n, 3] (object, first pair, pairs), code [m, 2] (op, arg), spectra [k, 30],
+    vectors [k, 3], scalars [k], textures (list of uint8 [h, w, bpp])."""
+    code, spectra, vectors, scalars, textures, programs = [], [], [], [], [], []
+
+    def emit(e):
+        k = e[0]
+        if k == "S":
+            spectra.append(np.asarray(e[1], dtype=np.float64)); code.append((OP_SPEC, len(spectra) - 1))
+        elif k == "V":
+            vectors.append(np.asarray(e[1], dtype=np.float64)); code.append((OP_VEC, len(vectors) - 1))
+        elif k == "UV":
+            code.append((OP_UV, 0))
+        elif k == "IMG":
+            emit(e[2])
+            for i, t in enumerate(textures):
+                if t is e[1]:
+                    break
+            else:
+                textures.append(e[1]); i = len(textures) - 1
+            code.append((OP_IMAGE, i))
+        elif k == "CHK":
+            emit(e[2]); scalars.append(e[1]); code.append((OP_CHECKER, len(scalars) - 1))
+        elif k == "R2S":
+            emit(e[1]); code.append((OP_RGB2SPEC, 0))
+        else:
+            emit(e[1]); emit(e[2])
+            code.append(({"ADDS": OP_ADD_S, "MULS": OP_MUL_S, "ADDV": OP_ADD_V, "MULV": OP_MUL_V}[k], 0))
+
+    for obj, r in enumerate(records):
+        if r.get("graph") is None:
+            continue
+        begin = len(code)
+        emit(r["graph"])
+        programs.append((obj, begin, len(code) - begin))
+    if not programs:
+        return None
+    return {"programs": np.asarray(programs, dtype=np.uint32).reshape(-1, 3), "code": np.asarray(code, dtype=np.uint32).reshape(-1, 2),
+            "spectra": np.asarray(spectra, dtype=np.float64).reshape(-1, NBINS), "vectors": np.asarray(vectors, dtype=np.float64).reshape(-1, 3),
+            "scalars": np.asarray(scalars, dtype=np.float64).reshape(-1), "textures": textures}
 
 
 def load_materials(path):

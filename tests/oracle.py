@@ -185,7 +185,28 @@ class Scene:
             for k in range(NBINS):
                 arr[i].a[k] = float(m["a"][k])
                 arr[i].b[k] = float(m["b"][k])
-        return lib().orc_scene_set_materials(self.h, arr, len(records))
+        rc = lib().orc_scene_set_materials(self.h, arr, len(records))
+        self.set_material_graphs(records)
+        return rc
+
+    def set_material_graphs(self, records):
+        """per-hit graphs of the records that carry one (NodeMaterial.record()["graph"]); clears them otherwise"""
+        from ray_tracer_amd import scene_io
+        L = lib()
+        vp, u32 = C.c_void_p, C.c_uint32
+        L.orc_scene_set_material_graphs.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, vp, vp, vp, u32]
+        g = scene_io.compile_material_graphs(records)
+        if g is None:
+            return L.orc_scene_set_material_graphs(self.h, None, 0, None, 0, None, 0, None, 0, None, 0, None, None, None, None, 0)
+        tex = [np.ascontiguousarray(t, dtype=np.uint8) for t in g["textures"]]
+        n = len(tex)
+        ptrs = (C.c_void_p * max(n, 1))(*[t.ctypes.data for t in tex])
+        w = (C.c_int * max(n, 1))(*[t.shape[1] for t in tex])
+        h = (C.c_int * max(n, 1))(*[t.shape[0] for t in tex])
+        bpp = (C.c_int * max(n, 1))(*[t.shape[2] for t in tex])
+        return L.orc_scene_set_material_graphs(self.h, _p(g["programs"]), len(g["programs"]), _p(g["code"]), len(g["code"]),
+                                               _p(g["spectra"]), len(g["spectra"]), _p(g["vectors"]), len(g["vectors"]),
+                                               _p(g["scalars"]), len(g["scalars"]), ptrs, w, h, bpp, n)
 
     def set_environment(self, texels, brightness=0.5):
         L = lib()

@@ -70,12 +70,25 @@ def test_material_folding(cornell_dir):
     # a graph with nothing wired to the output is a null BSDF
     none = scene_io.NodeMaterial({"name": "x", "nodes": [{"type": "UV"}, {"type": "Output"}], "connections": []})
     assert none.record()["type"] == capi.MAT_NONE
-    # a texture-driven albedo needs per-hit evaluation: refused, not silently flattened
+    # an ImageTexture without a file leaves its output untouched (materialnode.cpp:1003-1004): the albedo folds to zero
     tex = {"name": "t", "nodes": [{"type": "UV"}, {"type": "Output"}, {"type": "Lambertian", "albedo": [1] * 30},
                                   {"type": "RGBtoSpectrum"}, {"type": "ImageTexture"}],
            "connections": [{"input_node": 1, "input_slot": "BSDF", "output_node": 2, "output_slot": "BSDF"},
                            {"input_node": 2, "input_slot": "albedo", "output_node": 3, "output_slot": "Spectrum"},
                            {"input_node": 3, "input_slot": "RGB", "output_node": 4, "output_slot": "Out"}]}
+    flat = scene_io.NodeMaterial(tex).record()
+    assert "graph" not in flat and not flat["a"].any()
+    # with a texture and the UV node wired in, the albedo becomes a per-hit program instead of a constant
+    tex["nodes"][4]["path"] = "mem"
+    tex["connections"].append({"input_node": 4, "input_slot": "UV", "output_node": 0, "output_slot": "Out->"})
+    texels = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)
+    rec = scene_io.NodeMaterial(tex, textures={"mem": texels}).record()
+    assert rec["graph"][0] == "R2S" and rec["graph"][1][0] == "IMG" and rec["graph"][1][2] == ("UV",)
+    g = scene_io.compile_material_graphs([flat, rec])
+    assert g["programs"].tolist() == [[1, 0, 3]] and g["code"].tolist() == [[scene_io.OP_UV, 0], [scene_io.OP_IMAGE, 0], [scene_io.OP_RGB2SPEC, 0]]
+    assert scene_io.compile_material_graphs([flat]) is None
+    # nodes that are not evaluated on the device are refused, not silently flattened
+    tex["nodes"][4] = {"type": "ValueNoise"}
     with pytest.raises(scene_io.UnsupportedMaterialGraph):
         scene_io.NodeMaterial(tex).record()
     # Dielectric: the "surface_color" lookup never matches the slot "surface color" -> own array
