@@ -1,5 +1,7 @@
 #include "materialnode.h"
 #include <cstring>
+#include <fstream>
+#include <sstream>
 
 namespace mi355host {
 
@@ -107,6 +109,193 @@ std::vector<double> NodeMaterial::SlotSpectrum(int node, const char *slot, const
 	return ComputeSpectrum(p, 0);
 }
 
+// ---- per-hit graphs: the same walks as above, but a sub-graph that reads the hit's texture coordinate becomes an expression
+struct NodeMaterial::Expr {
+	char kind = 'S'; // S spectrum constant, V vector constant, U uv, I image, C checker, R rgb->spectrum, + * on spectra, p m on vectors
+	std::vector<double> val;
+	double size = 0.0;
+	std::string path;
+	std::shared_ptr<Expr> a, b;
+	bool constant() const { return kind == 'S' || kind == 'V'; }
+};
+
+namespace {
+bool read_ppm(const std::string &path, std::vector<uint8_t> &texels, int &w, int &h)
+{
+	std::ifstream f(path, std::ios::binary);
+	if (!f) return false;
+	std::string magic;
+	f >> magic;
+	if (magic != "P6") throw UnsupportedMaterialGraph("texture " + path + ": only binary PPM files can be decoded here");
+	int vals[3], n = 0;
+	while (n < 3) {
+		f >> std::ws;
+		if (f.peek() == '#') { std::string skip; std::getline(f, skip); continue; }
+		if (!(f >> vals[n])) return false;
+		n++;
+	}
+	f.get(); // the single whitespace after maxval
+	w = vals[0]; h = vals[1];
+	texels.resize((size_t)w * h * 3);
+	f.read(reinterpret_cast<char *>(texels.data()), (std::streamsize)texels.size());
+	return (size_t)f.gcount() == texels.size();
+}
+} // namespace
+
+std::shared_ptr<NodeMaterial::Expr> NodeMaterial::VecExpr(int node, int depth) const
+{
+	if (depth > 64) throw UnsupportedMaterialGraph("cyclic material graph in " + name);
+	const std::string t = nodes[node].at("type").string_or("");
+	auto e = std::make_shared<Expr>();
+	e->kind = 'V';
+	e->val = {0.0, 0.0, 0.0};
+	if (t == "RGBColor") { e->val = ComputeVec3(node, depth); return e; } // :931-936
+	if (t == "UV") { e->kind = 'U'; return e; }                            // :893-896
+	if (t == "ImageTexture") { // :1001-1018
+		std::string path = nodes[node].contains("path") ? nodes[node].at("path").string_or("") : "";
+		int p = Parent(node, "UV");
+		std::ifstream probe(path, std::ios::binary);
+		if (path.empty() || !probe || p < 0) return e;
+		e->kind = 'I';
+		e->path = path;
+		e->a = VecExpr(p, depth + 1);
+		return e;
+	}
+	if (t == "Checkerboard") { // :1046-1063
+		int p = Parent(node, "UV");
+		if (p < 0) return e;
+		e->kind = 'C';
+		e->size = nodes[node].at("size").number(1.0);
+		e->a = VecExpr(p, depth + 1);
+		return e;
+	}
+	if (t == "Addition" || t == "Multiplication") { // the dvec3 overloads, :1098-1102 and :1195-1198
+		const bool add = t == "Addition";
+		int p0 = Parent(node, "In0"), p1 = Parent(node, "In1");
+		if (p0 < 0) return e;
+		auto a = VecExpr(p0, depth + 1);
+		if (p1 < 0) return add ? a : e;
+		auto b = VecExpr(p1, depth + 1);
+		if (a->kind == 'V' && b->kind == 'V') {
+			for (int i = 0; i < 3; i++) e->val[i] = add ? a->val[i] + b->val[i] : a->val[i] * b->val[i];
+			return e;
+		}
+		e->kind = add ? 'p' : 'm';
+		e->a = a;
+		e->b = b;
+		return e;
+	}
+	if (t == "RodriguesRotation" || t == "CombineVec3Component" || t == "ValueNoise" || t == "ValueNoise2D" || t == "AccessVec3Component" ||
+	    t == "RandomSampling")
+		throw UnsupportedMaterialGraph("node " + t + " of material " + name + " is not evaluated on the device");
+	return e; // no dvec3 Compute: the base class leaves the caller's vector untouched (:81-83)
+}
+
+std::shared_ptr<NodeMaterial::Expr> NodeMaterial::SpecExpr(int node, int depth) const
+{
+	if (depth > 64) throw UnsupportedMaterialGraph("cyclic material graph in " + name);
+	const std::string t = nodes[node].at("type").string_or("");
+	auto e = std::make_shared<Expr>();
+	e->kind = 'S';
+	e->val.assign(N, 0.0);
+	if (t == "RGBtoSpectrum") { // :949-957
+		int p = Parent(node, "RGB");
+		if (p < 0) return e;
+		auto v = VecExpr(p, depth + 1);
+		if (v->kind == 'V') {
+			for (int i = 0; i < N; i++) e->val[i] = i < N / 3 ? v->val[2] : (i < 2 * N / 3 ? v->val[1] : v->val[0]);
+			return e;
+		}
+		e->kind = 'R';
+		e->a = v;
+		return e;
+	}
+	if (t == "Addition" || t == "Multiplication") {
+		const bool add = t == "Addition";
+		int p0 = Parent(node, "In0"), p1 = Parent(node, "In1");
+		if (p0 < 0) return e;
+		auto a = SpecExpr(p0, depth + 1);
+		if (p1 < 0) return add ? a : e;
+		auto b = SpecExpr(p1, depth + 1);
+		if (a->kind == 'S' && b->kind == 'S') {
+			for (int i = 0; i < N; i++) e->val[i] = add ? a->val[i] + b->val[i] : a->val[i] * b->val[i];
+			return e;
+		}
+		e->kind = add ? '+' : '*';
+		e->a = a;
+		e->b = b;
+		return e;
+	}
+	e->val = ComputeSpectrum(node, depth); // every other node: the constant walk
+	return e;
+}
+
+std::shared_ptr<NodeMaterial::Expr> NodeMaterial::SlotExpr(void) const
+{
+	if ((int)nodes.size() <= Output_i) return nullptr;
+	int b = Parent(Output_i, "BSDF");
+	if (b < 0) return nullptr;
+	const std::string t = nodes[b].at("type").string_or("");
+	const char *slot = t == "Lambertian" || t == "ColoredMetal" ? "albedo" : (t == "DiffuseLight" ? "color" : nullptr);
+	if (!slot) return nullptr;
+	int p = Parent(b, slot);
+	if (p < 0) return nullptr; // the node's own array
+	return SpecExpr(p, 0);
+}
+
+bool NodeMaterial::EmitGraph(uint32_t object, MaterialGraphTables &out) const
+{
+	auto root = SlotExpr();
+	if (!root || root->constant()) return false;
+	const uint32_t begin = (uint32_t)(out.code.size() / 2);
+	struct Emit {
+		MaterialGraphTables &o;
+		void op(uint32_t k, uint32_t arg) { o.code.push_back(k); o.code.push_back(arg); }
+		void run(const Expr &e)
+		{
+			switch (e.kind) {
+			case 'S': o.spectra.insert(o.spectra.end(), e.val.begin(), e.val.end()); op(0, (uint32_t)(o.spectra.size() / N - 1)); break;
+			case 'V': o.vectors.insert(o.vectors.end(), e.val.begin(), e.val.end()); op(1, (uint32_t)(o.vectors.size() / 3 - 1)); break;
+			case 'U': op(2, 0); break;
+			case 'I': {
+				run(*e.a);
+				uint32_t k = 0;
+				for (; k < o.texture_paths.size(); k++) if (o.texture_paths[k] == e.path) break;
+				if (k == o.texture_paths.size()) {
+					std::vector<uint8_t> px;
+					int w = 0, h = 0;
+					if (!read_ppm(e.path, px, w, h)) throw UnsupportedMaterialGraph("texture " + e.path + " cannot be read");
+					o.texels.push_back(std::move(px));
+					o.textures.push_back(rt_texture{nullptr, w, h, 3});
+					o.texture_paths.push_back(e.path);
+				}
+				op(5, k);
+				break;
+			}
+			case 'C': run(*e.a); o.scalars.push_back(e.size); op(6, (uint32_t)(o.scalars.size() - 1)); break;
+			case 'R': run(*e.a); op(7, 0); break;
+			default: run(*e.a); run(*e.b); op(e.kind == '+' ? 8 : e.kind == '*' ? 9 : e.kind == 'p' ? 10 : 11, 0); break;
+			}
+		}
+	} emit{out};
+	emit.run(*root);
+	out.programs.push_back(rt_graph_program{object, begin, (uint32_t)(out.code.size() / 2) - begin});
+	return true;
+}
+
+rt_material_graphs MaterialGraphTables::View(void)
+{
+	for (size_t i = 0; i < textures.size(); i++) textures[i].texels = texels[i].data();
+	rt_material_graphs g;
+	g.programs = programs.data(); g.n_programs = (uint32_t)programs.size();
+	g.code = code.data(); g.n_code = (uint32_t)(code.size() / 2);
+	g.spectra = spectra.data(); g.n_spectra = (uint32_t)(spectra.size() / N);
+	g.vectors = vectors.data(); g.n_vectors = (uint32_t)(vectors.size() / 3);
+	g.scalars = scalars.data(); g.n_scalars = (uint32_t)scalars.size();
+	g.textures = textures.data(); g.n_textures = (uint32_t)textures.size();
+	return g;
+}
+
 rt_material NodeMaterial::Record() const
 {
 	rt_material r;
@@ -118,14 +307,19 @@ rt_material NodeMaterial::Record() const
 	if (b < 0) return r;
 	const std::string t = nodes[b].at("type").string_or("");
 	std::vector<double> a(N, 0.0), bb(N, 0.0);
-	if (t == "Lambertian") { r.type = RT_MAT_LAMBERTIAN; a = SlotSpectrum(b, "albedo", "albedo"); }
-	else if (t == "DiffuseLight") { r.type = RT_MAT_DIFFUSE_LIGHT; a = SlotSpectrum(b, "color", "color"); }
+	auto slot_a = [&](const char *slot) { // constant: the folded spectrum; per hit: zeros, EmitGraph supplies the program
+		auto e = SlotExpr();
+		if (!e) return SlotSpectrum(b, slot, slot);
+		return e->constant() ? e->val : std::vector<double>(N, 0.0);
+	};
+	if (t == "Lambertian") { r.type = RT_MAT_LAMBERTIAN; a = slot_a("albedo"); }
+	else if (t == "DiffuseLight") { r.type = RT_MAT_DIFFUSE_LIGHT; a = slot_a("color"); }
 	else if (t == "Dielectric") { // "surface_color" never matches the slot "surface color" (:300,359)
 		r.type = RT_MAT_DIELECTRIC;
 		a = own_array(nodes[b], "n");
 		bb = SlotSpectrum(b, "surface_color", "surface_color");
 	} else if (t == "Conductor") { r.type = RT_MAT_CONDUCTOR; a = own_array(nodes[b], "n"); bb = own_array(nodes[b], "k"); }
-	else if (t == "ColoredMetal") { r.type = RT_MAT_COLORED_METAL; a = SlotSpectrum(b, "albedo", "albedo"); }
+	else if (t == "ColoredMetal") { r.type = RT_MAT_COLORED_METAL; a = slot_a("albedo"); }
 	else if (t == "GGXReflection")
 		throw UnsupportedMaterialGraph("GGXReflection reads an uninitialised alpha and returns no value from BSDF()/PDF() in the reference");
 	else throw UnsupportedMaterialGraph("node type " + t + " wired to the BSDF output of " + name);

@@ -15,13 +15,30 @@ struct UnsupportedMaterialGraph : std::runtime_error {
 	using std::runtime_error::runtime_error;
 };
 
+// tables of rt_upload_material_graphs, filled by NodeMaterial::EmitGraph for every object whose albedo / color slot
+// reads the hit's texture coordinate
+struct MaterialGraphTables {
+	std::vector<rt_graph_program> programs;
+	std::vector<uint32_t> code; // (op, arg) pairs
+	std::vector<double> spectra, vectors, scalars;
+	std::vector<std::vector<uint8_t>> texels; // one buffer per texture, with its descriptor below
+	std::vector<rt_texture> textures;
+	std::vector<std::string> texture_paths;
+	rt_material_graphs View(void); // pointers into this object: keep it alive during the upload
+};
+
 class NodeMaterial {
 public:
 	explicit NodeMaterial(const Json &j);
 	std::string name;
 	bool light_flag = false;
-	// throws UnsupportedMaterialGraph for graphs that need the hit's texture coordinate (or GGXReflection)
+	// throws UnsupportedMaterialGraph for nodes that are not evaluated on the device (noise, rotation, component access, GGXReflection).
+	// When the albedo / color slot depends on the texture coordinate, `a` is zero and EmitGraph supplies the program.
 	rt_material Record() const;
+	// appends this material's per-hit program for `object` to the tables; false when its slot is a constant.
+	// ImageTexture files are read as binary PPM (the reference decodes with stb_image); a missing file leaves zeros
+	// as the reference's null texture does (materialnode.cpp:1003-1004)
+	bool EmitGraph(uint32_t object, MaterialGraphTables &out) const;
 
 private:
 	struct Conn { int input_node, output_node; std::string input_slot, output_slot; };
@@ -31,6 +48,10 @@ private:
 	std::vector<double> ComputeSpectrum(int node, int depth) const;
 	std::vector<double> ComputeVec3(int node, int depth) const;
 	std::vector<double> SlotSpectrum(int node, const char *slot, const char *own_key) const;
+	struct Expr;
+	std::shared_ptr<Expr> VecExpr(int node, int depth) const;
+	std::shared_ptr<Expr> SpecExpr(int node, int depth) const;
+	std::shared_ptr<Expr> SlotExpr(void) const; // the expression of the BSDF node's albedo / color slot, null for other nodes
 };
 
 // Scene::LoadMaterial (scene.cpp:249-265) and Scene::LoadObjMatMap (scene.cpp:282-300)

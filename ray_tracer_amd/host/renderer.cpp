@@ -65,6 +65,7 @@ bool Renderer::Upload(void)
 bool Renderer::LoadMaterials(const std::map<std::string, std::shared_ptr<NodeMaterial>> &materials) // renderer.cpp:24-44
 {
 	std::vector<rt_material> recs;
+	MaterialGraphTables graphs;
 	for (size_t i = 0; i < tables.object_names.size(); i++) { // obj objects in file order (as the reference), then PLY objects
 		auto itr = materials.find(tables.object_names[i]);
 		if (itr == materials.end()) {
@@ -72,9 +73,14 @@ bool Renderer::LoadMaterials(const std::map<std::string, std::shared_ptr<NodeMat
 			return false;
 		}
 		recs.push_back(itr->second->Record());
+		itr->second->EmitGraph((uint32_t)i, graphs); // per-hit program when the albedo / color slot reads the texture coordinate
 	}
 	if (!gpu) return false;
 	int rc = rt_upload_materials(gpu, recs.data(), (uint32_t)recs.size());
+	if (rc == RT_OK && !graphs.programs.empty()) {
+		rt_material_graphs view = graphs.View();
+		rc = rt_upload_material_graphs(gpu, &view);
+	}
 	if (rc != RT_OK) last_error = rt_last_error(gpu);
 	return rc == RT_OK; // RT_ERR_NO_LIGHTS: `light_objects.size() == 0` in the reference
 }

@@ -341,3 +341,70 @@ def test_material_graph_programs_are_validated(ctx, cornell_dir):
     assert upload([(0, 0)] * 5 + [(8, 0)] * 4) != capi.OK                  # deeper than four
     assert upload([(99, 0)]) != capi.OK                                    # unknown op
     assert upload([(0, 0), (0, 0), (9, 0)]) == capi.OK
+
+
+def test_cpp_host_compiles_material_graphs_like_the_python_host(ctx, cornell_dir, tmp_path):
+    """a materials file with a checkerboard and a PPM image texture on the white and green materials: the C++ host (rt_cli) and the
+    Python host compile the graphs and render the same film"""
+    import json
+    import os
+    import subprocess
+    from ray_tracer_amd import scene_io
+    rng = np.random.default_rng(4)
+    tex = rng.integers(40, 256, (6, 10, 3), dtype=np.uint8)
+    ppm = tmp_path / "tex.ppm"
+    ppm.write_bytes(b"P6\n# made by the test\n10 6\n255\n" + tex.tobytes())
+    mats = json.load(open(os.path.join(cornell_dir, "materials.json")))
+
+    def rewire(m, feed_nodes, feed_conns):
+        """feeds the albedo slot of the material's Lambertian node (found through the BSDF connection) from new nodes"""
+        bsdf = next(c["output_node"] for c in m["connections"] if c["input_node"] == 1 and c["input_slot"].startswith("BSDF"))
+        m["connections"] = [c for c in m["connections"] if not (c["input_node"] == bsdf and c["input_slot"].startswith("albedo"))]
+        base = len(m["nodes"])
+        for n in feed_nodes:
+            n.setdefault("name", n["type"])
+            n.setdefault("input_slots", [])
+            n.setdefault("output_slots", [])
+            n.setdefault("pos", {"x": 0, "y": 0})
+        m["nodes"] += feed_nodes
+        for c in feed_conns:
+            c["output_node"] = c["output_node"] + base if c["output_node"] >= 0 else 0  # -1 stands for the UV node (index 0)
+            c["input_node"] = c["input_node"] + base if c["input_node"] >= 0 else bsdf
+        m["connections"] += feed_conns
+
+    by_name = {m["name"]: m for m in mats}
+    rewire(by_name["white"], [{"type": "RGBtoSpectrum"}, {"type": "Checkerboard", "size": 0.2}],
+           [{"output_node": 0, "output_slot": "Spectrum", "input_node": -1, "input_slot": "albedo"},
+            {"output_node": 1, "output_slot": "Out", "input_node": 0, "input_slot": "RGB"},
+            {"output_node": -1, "output_slot": "Out->", "input_node": 1, "input_slot": "UV"}])
+    rewire(by_name["green"], [{"type": "RGBtoSpectrum"}, {"type": "ImageTexture", "path": str(ppm)}],
+           [{"output_node": 0, "output_slot": "Spectrum", "input_node": -1, "input_slot": "albedo"},
+            {"output_node": 1, "output_slot": "Out", "input_node": 0, "input_slot": "RGB"},
+            {"output_node": -1, "output_slot": "Out->", "input_node": 1, "input_slot": "UV"}])
+    mpath = tmp_path / "materials.json"
+    mpath.write_text(json.dumps(mats))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "ray_tracer_amd", "lib", "rt_cli")
+    out = tmp_path / "film.f64"
+    subprocess.run([cli, "--obj", os.path.join(cornell_dir, "cornell_box_triangulated.obj"), "--materials", str(mpath), "--objmatmap",
+                    os.path.join(cornell_dir, "objmatmap.json"), "--width", "40", "--height", "30", "--sample", "4", "--algorithm", "mis",
+                    "--seed", "78", "--film", str(out)], check=True, timeout=120)
+    got = np.fromfile(out, dtype=np.float64).reshape(-1, 30)
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 40, 30)
+    named = scene_io.load_materials(str(mpath))
+    omm = scene_io.load_objmatmap(os.path.join(cornell_dir, "objmatmap.json"))
+    recs = [named[omm[n]].record() for n in mesh["names"]]
+    assert sum("graph" in r for r in recs) >= 2
+    ctx.upload_mesh(mesh)
+    ctx.upload_materials(recs)
+    ctx.set_camera(cam)
+    ctx.render_begin(40, 30, 4, 30, capi.ALG_MIS, 78)
+    ctx.render_pass(0, 4)
+    ctx.render_sync()
+    want = ctx.download_film()
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-9)
+    ctx.upload_materials(records)
+    ctx.render_begin(40, 30, 4, 30, capi.ALG_MIS, 78)
+    ctx.render_pass(0, 4)
+    ctx.render_sync()
+    assert np.abs(ctx.download_film() - want).sum() > 0.1 * want.sum()  # the graphs changed the picture
