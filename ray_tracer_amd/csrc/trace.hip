@@ -25,7 +25,10 @@ namespace {
 #define TRACE_REFILL_MIN 8
 #endif
 #ifndef TRACE_NODE_MIN_LANES
-#define TRACE_NODE_MIN_LANES 40
+#define TRACE_NODE_MIN_LANES 56
+#endif
+#ifndef TRACE_COOP_LEAF
+#define TRACE_COOP_LEAF 1
 #endif
 #ifndef TRACE_WAVES_PER_SIMD
 #define TRACE_WAVES_PER_SIMD 4
@@ -120,6 +123,10 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 #define TRACE_COUNT(iter, lanes) do { if (lane == __ffsll((long long)__ballot(true)) - 1) iter++; lanes++; } while (0)
 #else
 #define TRACE_COUNT(iter, lanes) do { } while (0)
+#endif
+#if TRACE_COOP_LEAF
+	__shared__ uint32_t coop_li[kBlock / 64][64], coop_owner[kBlock / 64][64];
+	__shared__ unsigned long long coop_t[kBlock / 64][64], coop_id[kBlock / 64][64];
 #endif
 	__shared__ uint32_t lds_base[LDS_STACK ? kLdsStack * kBlock : 1];
 	__shared__ uint32_t lds_mask[LDS_STACK ? kLdsStack * kBlock : 1];
@@ -282,6 +289,110 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				if (__ballot(l0_hits == 0) == 0) break; // every lane still descending already holds triangles to test
 				if (TRACE_NODE_MIN_LANES > 0 && __popcll(__ballot(true)) < TRACE_NODE_MIN_LANES) break; // too few lanes left descending
 			}
+#if TRACE_COOP_LEAF
+		}
+		// ---- triangle phase, shared by the whole wave.  Lanes hold very different numbers of parked triangles (0 to 8 and more), so
+		// a per-lane loop runs the fp64 tests with a quarter of the lanes.  Instead every (ray, triangle) pair of the wave gets a lane of
+		// its own: pairs are numbered by a prefix sum over the per-lane counts, written to LDS (leaf position + owner lane), and lane j
+		// tests pair j with the owner's ray fetched by cross-lane reads.  Hits are merged per owner with LDS atomics: minimum of the
+		// bit pattern of t (positive doubles order like their bits), then, among the hits at that t, minimum of (fan triangle << 32 | leaf
+		// position), which is the tie rule "lowest fan triangle".  Idle lanes take part as workers.
+		{
+			const int wv = threadIdx.x >> 6;
+			uint32_t n_mine = 0;
+			if (active) {
+				for (uint32_t h = l0_hits; h; h &= h - 1u) { const uint32_t c = (uint32_t)__ffs((int)h) - 1u; n_mine += (((c < 4 ? l0_m0 : l0_m1) >> (8 * (c & 3))) & 0xFFu) >> 5; }
+				for (uint32_t h = l1_hits; h; h &= h - 1u) { const uint32_t c = (uint32_t)__ffs((int)h) - 1u; n_mine += (((c < 4 ? l1_m0 : l1_m1) >> (8 * (c & 3))) & 0xFFu) >> 5; }
+			}
+			uint32_t incl = n_mine;
+#pragma unroll
+			for (int dlt = 1; dlt < 64; dlt <<= 1) {
+				const uint32_t up = (uint32_t)__shfl_up((int)incl, dlt);
+				if (lane >= dlt) incl += up;
+			}
+			const uint32_t off = incl - n_mine, total = (uint32_t)__shfl((int)incl, 63);
+			if (total != 0) {
+				const unsigned long long none_id = ~0ull;
+				unsigned long long my_t = (unsigned long long)__double_as_longlong(t_best);
+				unsigned long long my_id = best == RT_MISS ? none_id : (((unsigned long long)best_tri << 32) | best);
+				if (n_mine) { coop_t[wv][lane] = my_t; coop_id[wv][lane] = my_id; }
+				for (uint32_t r0 = 0; r0 < total; r0 += 64) {
+					// owners publish the pairs of this round
+					if (n_mine && off < r0 + 64 && off + n_mine > r0) {
+						uint32_t q = off;
+						for (int grp = 0; grp < 2; grp++) {
+							const uint32_t gb = grp ? l1_base : l0_base, m0 = grp ? l1_m0 : l0_m0, m1 = grp ? l1_m1 : l0_m1;
+							for (uint32_t h = grp ? l1_hits : l0_hits; h; h &= h - 1u) {
+								const uint32_t c = (uint32_t)__ffs((int)h) - 1u;
+								const uint32_t meta = ((c < 4 ? m0 : m1) >> (8 * (c & 3))) & 0xFFu;
+								const uint32_t first = gb + (meta & 31u), count = meta >> 5;
+								for (uint32_t k = 0; k < count; k++, q++)
+									if (q - r0 < 64u) { coop_li[wv][q - r0] = first + k; coop_owner[wv][q - r0] = (uint32_t)lane; }
+							}
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					// workers: one pair each
+					const bool work = r0 + (uint32_t)lane < total;
+					const uint32_t o = work ? coop_owner[wv][lane] : (uint32_t)lane;
+					const uint32_t li = work ? coop_li[wv][lane] : 0u;
+					RayD r;
+					r.ox = __shfl(ox, (int)o); r.oy = __shfl(oy, (int)o); r.oz = __shfl(oz, (int)o);
+					r.dx = __shfl(dx, (int)o); r.dy = __shfl(dy, (int)o); r.dz = __shfl(dz, (int)o);
+					r.tmin = __shfl(tmin_f, (int)o);
+					bool hit = false;
+					unsigned long long bits = 0, id = 0;
+					if (work) {
+						TRACE_COUNT(st_leaf_iter, st_leaf_lanes);
+						const double cur_best = __longlong_as_double((long long)coop_t[wv][o]);
+						// both halves of the record are requested at once: nine in ten plane distances lie in range and need the
+						// second half, and one memory latency per round instead of two is worth the few wasted lines
+						const double2 a0 = g.tri_a[3 * (size_t)li], a1 = g.tri_a[3 * (size_t)li + 1], a2 = g.tri_a[3 * (size_t)li + 2];
+						const double2 b0 = g.tri_b[3 * (size_t)li], b1 = g.tri_b[3 * (size_t)li + 1], b2 = g.tri_b[3 * (size_t)li + 2];
+						// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz); b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
+						const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
+						if (t >= r.tmin && t <= cur_best) {
+							TRACE_COUNT(st_in_iter, st_in_lanes);
+							if (inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) {
+								hit = true;
+								bits = (unsigned long long)__double_as_longlong(t + 0.0); // -0.0 -> +0.0: keeps bit order = numeric order
+								id = ANY ? 0ull : (((unsigned long long)g.leaf_tri[li] << 32) | li);
+								__hip_atomic_fetch_min(&coop_t[wv][o], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+							}
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					// an owner whose t came down forgets the triangle it held; then the hits at the minimum settle the tie
+					if (n_mine && coop_t[wv][lane] != my_t) { my_t = coop_t[wv][lane]; coop_id[wv][lane] = none_id; }
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					if (hit && bits == coop_t[wv][o]) __hip_atomic_fetch_min(&coop_id[wv][o], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+				}
+				if (n_mine) {
+					const unsigned long long fin = coop_id[wv][lane];
+					if (fin != my_id) { // something was hit that beats what the lane held
+						if (ANY) found_any = true;
+						else {
+							t_best = __longlong_as_double((long long)my_t);
+							best = (uint32_t)fin;
+							best_tri = (uint32_t)(fin >> 32);
+							const double ts = t_best * (double)rscale;
+							float tf = (float)ts;
+							if ((double)tf < ts) tf = next_up(tf);
+							tfar_f = tf;
+						}
+					}
+					l0_hits = 0;
+					l1_hits = 0;
+				}
+			}
+		}
+		if (active) {
+#else
 			// ---- triangle phase: both parked groups
 			if (l0_hits != 0) {
 				RayD r;
@@ -321,6 +432,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					}
 				}
 			}
+#endif
 			// ---- finished: write the result, free the lane
 			const bool out_of_nodes = (g_mask & 0xFFu) == 0 && sp == 0;
 			if ((ANY && found_any) || (out_of_nodes && l0_hits == 0 && l1_hits == 0)) {
