@@ -93,6 +93,9 @@ constexpr int kMaxBounces = 62; // counter slots per batch; a longer path wraps 
 #ifndef SHADE_BLOCK
 #define SHADE_BLOCK 512
 #endif
+#ifndef BDPT_BATCH_LOG2
+#define BDPT_BATCH_LOG2 25
+#endif
 #ifndef SHADE_MIN_BLOCKS
 #define SHADE_MIN_BLOCKS 1
 #endif
@@ -452,10 +455,39 @@ __device__ __forceinline__ Slots reserve_slots(unsigned long long *tails, bool s
 // ---------------------------------------------------------------------------------------------
 // generate: pixel jitter, band pick, thin-lens ray (renderer.cpp:81-94, camera.h:148-187)
 // ---------------------------------------------------------------------------------------------
+// NaiveBDPT records (used by render_bdpt.inc)
+constexpr int kBdptMax = 8;
+
+// Vertices are stored by depth: vertex k of the eye (light) subpath of sample `slot` sits at
+// [(k (+ kBdptMax)) * n_slots + slot], so that the walkers of one bounce, whose slots ascend, write next to each other
+// and the connection kernel reads each depth as one coalesced stream (per-sample runs of 16 x 48 bytes put every
+// 48-byte record on a line of its own).
+struct BdptVertex { // 48 bytes
+	float px, py, pz, nx, ny, nz, dx, dy, dz; // hit point, rec.normal, direction of the ray that arrived
+	float throughput;                          // alphas[e] / betas[l]
+	uint32_t object;
+	float a;                                   // slot a (albedo) of the vertex's material at this hit and band
+};
+
+struct BdptSample { // 64 bytes
+	uint64_t rng;
+	float weight; // film weight of the camera sample
+	uint32_t pixel;
+	uint32_t band_k_l; // band | K << 16 | L << 24
+	uint32_t last_eye_ray_hit;
+	uint32_t sel_face;
+	float pol[3];
+	float light_pdf_area, light_dir_pdf_projected, light_value;
+	float last_eye_vt[3]; // rec.vt of the eye subpath's last hit: what the reference evaluates the light's emission with (:558-560)
+};
+
+// BDPT: the pixel and the film weight go to the sample record, and the path state describes a subpath walker instead:
+// alpha (beta), the pending factor alpha_ (weight), the sample slot (pixel)
+template <bool BDPT>
 __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBand *__restrict__ bands, uint32_t n_bands,
                                                      int nx, int ny, int ns, int first_sample, uint64_t n_paths,
                                                      uint64_t seed, float tmin, rt_ray *__restrict__ rays,
-                                                     PathState *__restrict__ state)
+                                                     PathState *__restrict__ state, BdptSample *__restrict__ samples)
 {
 	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	if (idx >= n_paths) return;
@@ -492,6 +524,16 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBan
 	st.pixel = pixel;
 	st.band_bounce = k;
 	st.pad0 = st.pad1 = 0;
+	if (BDPT) {
+		BdptSample s{};
+		s.rng = st.rng;
+		s.weight = st.weight;
+		s.pixel = pixel;
+		s.band_k_l = k;
+		samples[idx] = s;
+		st.weight = 1.0f;
+		st.pixel = (uint32_t)idx;
+	}
 	state[idx] = st;
 }
 
@@ -1080,8 +1122,8 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 		return e;
 	};
 	prof.begin(Profiler::GENERATE, n_paths, stream);
-	hipLaunchKernelGGL(k_generate, dim3((unsigned)((n_paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands,
-	                   im.n_bands, rs.nx, rs.ny, rs.ns, first_sample, n_paths, rs.seed, tmin, im.rays[0], im.state[0]);
+	hipLaunchKernelGGL(k_generate<false>, dim3((unsigned)((n_paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands,
+	                   im.n_bands, rs.nx, rs.ny, rs.ns, first_sample, n_paths, rs.seed, tmin, im.rays[0], im.state[0], (BdptSample *)nullptr);
 	prof.end(stream);
 	HIP_TRY(hipGetLastError());
 	rs.camera_samples += n_paths;
@@ -1192,7 +1234,8 @@ static hipError_t ensure_bdpt(Impl &im, uint64_t cap, hipStream_t stream, std::s
 	HIP_TRY(hipMalloc((void **)&im.bdpt_offsets, cap * sizeof(uint32_t)));
 	HIP_TRY(hipMalloc((void **)&im.bdpt_pairs, sizeof(unsigned long long)));
 	im.bdpt_scan_bytes = 0;
-	HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, im.bdpt_scan_bytes, im.bdpt_counts, im.bdpt_offsets, (int)cap, stream));
+	hipcub::TransformInputIterator<uint32_t, BdptSlotCount, const uint32_t *> slot_counts(im.bdpt_counts, BdptSlotCount());
+	HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, im.bdpt_scan_bytes, slot_counts, im.bdpt_offsets, (int)cap, stream));
 	HIP_TRY(hipMalloc(&im.bdpt_scan_tmp, std::max<size_t>(im.bdpt_scan_bytes, 1)));
 	im.bdpt_capacity = cap;
 	return hipSuccess;
@@ -1209,63 +1252,84 @@ static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &ge
 	BdptVertex *verts = static_cast<BdptVertex *>(im.bdpt_verts);
 	const unsigned blocks_n = (unsigned)((n_paths + kBlock - 1) / kBlock);
 	prof.begin(Profiler::GENERATE, n_paths, stream);
-	hipLaunchKernelGGL(k_generate, dim3(blocks_n), dim3(kBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns, first_sample,
-	                   n_paths, rs.seed, 0.001f, im.rays[0], im.state[0]);
-	hipLaunchKernelGGL(k_bdpt_init, dim3(blocks_n), dim3(kBlock), 0, stream, n, im.state[0], samples);
+	hipLaunchKernelGGL(k_generate<true>, dim3(blocks_n), dim3(kBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns, first_sample,
+	                   n_paths, rs.seed, 0.001f, im.rays[0], im.state[0], samples);
 	prof.end(stream);
 	HIP_TRY(hipGetLastError());
 	rs.camera_samples += n_paths;
-	// a subpath: trace, walk, repeat until no walker is left; the count of survivors is read back every bounce
-	auto walk = [&](bool light) -> hipError_t {
-		uint64_t live = n_paths;
-		int cur = 0;
-		for (int bounce = 0; live > 0; bounce++) {
-			if (bounce > 4 * kBdptMax) { err = "NaiveBDPT: a subpath does not end"; return hipErrorUnknown; }
-			HIP_TRY(hipMemsetAsync(im.counters, 0, 2 * sizeof(Counters), stream));
-			HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)im.counters, (int)live, 1, stream));
-			const uint32_t *n_live = reinterpret_cast<const uint32_t *>(&im.counters[0]);
-			prof.begin(Profiler::CLOSEST, live, stream);
-			HIP_TRY(launch_trace_closest(geom, im.rays[cur], live, im.hits, nullptr, stream, n_live));
+	// a subpath: trace, walk, repeat.  A walker that survives bounce b has stored b + 1 vertices, so nothing is left after
+	// kBdptMax + 1 bounces.  Counts stay on the device (slot base + b of the counters, read by the kernels of bounce b); the
+	// host only uses the copies that have already arrived to shrink the grids, and never waits for one.
+	struct WalkRec { long first = -1; int bounces = 0; };
+	auto walk = [&](bool light, int base, WalkRec &rec) -> hipError_t {
+		constexpr int nb = kBdptMax + 1;
+		static_assert(2 * (nb + 1) <= kMaxBounces + 2, "two subpaths' counters fit");
+		HIP_TRY(hipMemsetAsync(im.counters + base, 0, sizeof(Counters) * (nb + 1), stream));
+		HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(im.counters + base), (int)n, 1, stream));
+		im.h_counters[base].tails = n;
+		uint64_t bound = n_paths;
+		int known = 0, cur = 0;
+		for (int b = 0; b < nb; b++) {
+			while (known < b && hipEventQuery(im.ev[base + known + 1]) == hipSuccess) {
+				known++;
+				bound = std::min<uint64_t>(bound, (uint32_t)im.h_counters[base + known].tails);
+			}
+			if (bound == 0) break;
+			const uint32_t *n_live = reinterpret_cast<const uint32_t *>(&im.counters[base + b]);
+			prof.begin(Profiler::CLOSEST, bound, stream);
+			HIP_TRY(launch_trace_closest(geom, im.rays[cur], bound, im.hits, nullptr, stream, n_live));
 			prof.end(stream);
-			prof.begin(Profiler::SHADE, live, stream);
-			const dim3 grid((unsigned)((live + kShadeBlock - 1) / kShadeBlock));
+			if (b == 0) rec.first = prof.last();
+			prof.begin(Profiler::SHADE, bound, stream);
+			const dim3 grid((unsigned)((bound + kShadeBlock - 1) / kShadeBlock));
 			if (light)
 				hipLaunchKernelGGL((k_bdpt_walk<true>), grid, dim3(kShadeBlock), 0, stream, sh, n_live, im.rays[cur], im.state[cur], im.hits,
-				                   im.rays[cur ^ 1], im.state[cur ^ 1], &im.counters[1], samples, verts, rs.d_film);
+				                   im.rays[cur ^ 1], im.state[cur ^ 1], &im.counters[base + b + 1], samples, verts, n, im.bdpt_counts, rs.d_film);
 			else
 				hipLaunchKernelGGL((k_bdpt_walk<false>), grid, dim3(kShadeBlock), 0, stream, sh, n_live, im.rays[cur], im.state[cur], im.hits,
-				                   im.rays[cur ^ 1], im.state[cur ^ 1], &im.counters[1], samples, verts, rs.d_film);
+				                   im.rays[cur ^ 1], im.state[cur ^ 1], &im.counters[base + b + 1], samples, verts, n, im.bdpt_counts, rs.d_film);
 			prof.end(stream);
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipMemcpyAsync(&im.h_counters[1], &im.counters[1], sizeof(Counters), hipMemcpyDeviceToHost, stream));
-			HIP_TRY(hipStreamSynchronize(stream));
-			rs.closest_rays += live;
-			live = (uint32_t)im.h_counters[1].tails;
+			HIP_TRY(hipMemcpyAsync(&im.h_counters[base + b + 1], &im.counters[base + b + 1], sizeof(Counters), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipEventRecord(im.ev[base + b + 1], stream));
+			rec.bounces = b + 1;
 			cur ^= 1;
 		}
 		return hipSuccess;
 	};
-	hipError_t e = walk(false);
+	// exact counts once the stream has drained: statistics and the items of the profile records
+	auto settle = [&](int base, const WalkRec &rec) {
+		for (int b = 0; b < rec.bounces; b++) {
+			const uint64_t live = (uint32_t)im.h_counters[base + b].tails;
+			rs.closest_rays += live;
+			if (rec.first >= 0) { prof.set_items(rec.first + 2 * b, live); prof.set_items(rec.first + 2 * b + 1, live); }
+		}
+	};
+	WalkRec eye_rec, light_rec;
+	hipError_t e = walk(false, 0, eye_rec);
 	if (e != hipSuccess) return e;
 	prof.begin(Profiler::GENERATE, n_paths, stream);
 	hipLaunchKernelGGL(k_bdpt_light_start, dim3(blocks_n), dim3(kBlock), 0, stream, sh, n, samples, im.rays[0], im.state[0]);
 	prof.end(stream);
 	HIP_TRY(hipGetLastError());
-	e = walk(true);
+	e = walk(true, kBdptMax + 2, light_rec);
 	if (e != hipSuccess) return e;
 	// connection slots: count, scan, generate, trace, evaluate
 	HIP_TRY(hipMemsetAsync(im.bdpt_pairs, 0, sizeof(unsigned long long), stream));
-	hipLaunchKernelGGL(k_bdpt_count, dim3(blocks_n), dim3(kBlock), 0, stream, n, samples, im.bdpt_counts, im.bdpt_pairs);
+	hipLaunchKernelGGL(k_bdpt_pairs, dim3(std::min(blocks_n, 2048u)), dim3(kBlock), 0, stream, n, im.bdpt_counts, im.bdpt_pairs);
 	HIP_TRY(hipGetLastError());
 	size_t scan_bytes = im.bdpt_scan_bytes;
-	HIP_TRY(hipcub::DeviceScan::ExclusiveSum(im.bdpt_scan_tmp, scan_bytes, im.bdpt_counts, im.bdpt_offsets, (int)n, stream));
+	hipcub::TransformInputIterator<uint32_t, BdptSlotCount, const uint32_t *> slot_counts(im.bdpt_counts, BdptSlotCount());
+	HIP_TRY(hipcub::DeviceScan::ExclusiveSum(im.bdpt_scan_tmp, scan_bytes, slot_counts, im.bdpt_offsets, (int)n, stream));
 	uint32_t last_off = 0, last_cnt = 0;
 	unsigned long long pairs = 0;
 	HIP_TRY(hipMemcpyAsync(&last_off, im.bdpt_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 	HIP_TRY(hipMemcpyAsync(&last_cnt, im.bdpt_counts + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 	HIP_TRY(hipMemcpyAsync(&pairs, im.bdpt_pairs, sizeof(pairs), hipMemcpyDeviceToHost, stream));
 	HIP_TRY(hipStreamSynchronize(stream));
-	const uint64_t total = (uint64_t)last_off + last_cnt;
+	settle(0, eye_rec);
+	settle(kBdptMax + 2, light_rec);
+	const uint64_t total = (uint64_t)last_off + (last_cnt & 0xFFFFu);
 	if (total >= (1ull << 32)) { err = "NaiveBDPT: more than 2^32 connections in one batch"; return hipErrorInvalidValue; }
 	if (total > im.conn_capacity) { // about 4.6 slots per sample on the Cornell box; grown on demand, kept for later batches
 		const uint64_t want = total + total / 4;
@@ -1306,8 +1370,8 @@ hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample
 	// samples per batch: large batches amortise the nearly empty late bounces; queue memory is about 380 bytes per path (<= 2^25 paths, 12.7 GB)
 	if (rs.algorithm == RT_ALG_MIS_BDPT) return hipSuccess; // MISBDPT returns 0 for every sample (renderer.cpp:775-778): the film stays empty
 	const bool bdpt = rs.algorithm == RT_ALG_NAIVE_BDPT;
-	// NaiveBDPT keeps 16 subpath vertices per sample (832 bytes with the sample record): 2^22 samples per batch
-	uint64_t per_batch = std::max<uint64_t>(1, (1ull << (bdpt ? 22 : 25)) / std::max<uint64_t>(npix, 1));
+	// NaiveBDPT keeps 16 subpath vertices per sample (832 bytes with the sample record): 2^25 samples per batch (28 GB, plus about 14 GB of connection queues on the Cornell box): late bounces hold few walkers, and a small batch pays their launches for few samples (2^22: 454 spp/s, 2^24: 570, 2^25: 591 at 1080p)
+	uint64_t per_batch = std::max<uint64_t>(1, (1ull << (bdpt ? BDPT_BATCH_LOG2 : 25)) / std::max<uint64_t>(npix, 1));
 	if (npix * per_batch >= (1ull << 31)) per_batch = 1;
 	if (npix >= (1ull << 31)) { err = "image too large for 32-bit path indices"; return hipErrorInvalidValue; }
 	HIP_TRY(ensure_queues(im, npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1)), err));
