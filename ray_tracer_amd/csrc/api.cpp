@@ -110,10 +110,21 @@ void rt_destroy(rt_context *ctx)
 
 const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
+// render_pass may leave the last few paths of a batch for the next one; whatever reads the film or the counters, or changes
+// what those paths would see, finishes them first
+static int finish_pending_paths(rt_context *ctx)
+{
+	if (!ctx->render.begun) return RT_OK;
+	std::string err;
+	if (render_flush(ctx->render, ctx->geom, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
+	return RT_OK;
+}
+
 int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 {
 	if (!ctx || !mesh) return set_err(ctx, RT_ERR_INVALID, "rt_upload_mesh: NULL argument");
 	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (int rc = finish_pending_paths(ctx)) return rc;
 	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize")) return RT_ERR_HIP;
 	ctx->free_geometry();
 	ctx->has_materials = false;
@@ -221,6 +232,7 @@ int rt_upload_materials(rt_context *ctx, const rt_material *per_object, uint32_t
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_upload_materials: no mesh uploaded");
 	if (n_objects != ctx->host.n_objects) return set_err(ctx, RT_ERR_NO_MATERIAL, "rt_upload_materials: one record per obj object is required");
 	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (int rc = finish_pending_paths(ctx)) return rc;
 	for (uint32_t o = 0; o < n_objects; o++)
 		if (per_object[o].type < RT_MAT_NONE || per_object[o].type > RT_MAT_COLORED_METAL)
 			return set_err(ctx, RT_ERR_INVALID, "rt_upload_materials: unknown material type");
@@ -243,6 +255,7 @@ int rt_upload_material_graphs(rt_context *ctx, const rt_material_graphs *g)
 	if (!ctx) return RT_ERR_INVALID;
 	if (!ctx->has_materials) return set_err(ctx, RT_ERR_INVALID, "rt_upload_material_graphs: upload the material records first");
 	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (int rc = finish_pending_paths(ctx)) return rc;
 	if (g && g->n_programs) {
 		for (uint32_t t = 0; t < g->n_textures; t++)
 			if (!g->textures[t].texels || g->textures[t].width <= 0 || g->textures[t].height <= 0 || g->textures[t].bpp < 3)
@@ -294,6 +307,7 @@ int rt_set_environment(rt_context *ctx, const uint8_t *texels, int width, int he
 	if (!ctx) return RT_ERR_INVALID;
 	if (texels && (width <= 0 || height <= 0 || bpp < 3 || bpp > 4)) return set_err(ctx, RT_ERR_INVALID, "rt_set_environment: needs width, height > 0 and 3 or 4 bytes per texel");
 	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (int rc = finish_pending_paths(ctx)) return rc;
 	std::string err;
 	if (render_set_environment(ctx->render, texels, width, height, bpp, brightness, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	return RT_OK;
@@ -311,6 +325,7 @@ int rt_clear(rt_context *ctx)
 {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (int rc = finish_pending_paths(ctx)) return rc;
 	(void)hipStreamSynchronize(ctx->stream);
 	ctx->free_geometry();
 	ctx->has_materials = false;
@@ -408,6 +423,7 @@ int rt_render_sync(rt_context *ctx)
 {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (int rc = finish_pending_paths(ctx)) return rc;
 	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "render kernels")) return RT_ERR_HIP;
 	return RT_OK;
 }
@@ -417,6 +433,7 @@ int rt_download_film(rt_context *ctx, double *spectrum_img)
 	if (!ctx || !spectrum_img) return set_err(ctx, RT_ERR_INVALID, "rt_download_film: NULL argument");
 	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_download_film: nothing rendered");
 	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (int rc = finish_pending_paths(ctx)) return rc;
 	std::string err;
 	if (render_download_film(ctx->render, spectrum_img, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	return RT_OK;
@@ -427,6 +444,7 @@ int rt_download_preview(rt_context *ctx, int samples_done, double *preview_img)
 	if (!ctx || !preview_img) return set_err(ctx, RT_ERR_INVALID, "rt_download_preview: NULL argument");
 	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_download_preview: nothing rendered");
 	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (int rc = finish_pending_paths(ctx)) return rc;
 	std::string err;
 	if (render_download_preview(ctx->render, samples_done, preview_img, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	return RT_OK;
@@ -444,6 +462,7 @@ int rt_film_device_ptr(rt_context *ctx, void **d_film, size_t *bytes)
 int rt_get_stats(rt_context *ctx, rt_stats *out)
 {
 	if (!ctx || !out) return RT_ERR_INVALID;
+	if (ctx->render.begun && use_device(ctx)) { if (int rc = finish_pending_paths(ctx)) return rc; }
 	std::memset(out, 0, sizeof(*out));
 	out->n_faces = ctx->host.n_faces;
 	out->n_triangles = ctx->host.n_tris;
@@ -517,6 +536,7 @@ int rt_profile_stop(rt_context *ctx, rt_profile *out)
 {
 	if (!ctx || !out) return RT_ERR_INVALID;
 	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (int rc = finish_pending_paths(ctx)) return rc;
 	ctx->profiler.enabled = false;
 	ctx->profiler.collect(*out);
 	return RT_OK;
@@ -525,6 +545,7 @@ int rt_profile_stop(rt_context *ctx, rt_profile *out)
 int rt_render_capture_rays(rt_context *ctx, rt_ray *buf, uint64_t capacity, uint64_t *n_captured)
 {
 	if (!ctx) return RT_ERR_INVALID;
+	if (ctx->render.begun && use_device(ctx)) { if (int rc = finish_pending_paths(ctx)) return rc; }
 	ctx->render.capture_buf = buf;
 	ctx->render.capture_capacity = buf ? capacity : 0;
 	ctx->render.capture_count = 0;

@@ -98,6 +98,8 @@ hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const
 hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, int ns, int spectral_samples, int algorithm,
                         uint64_t seed, void *d_film, hipStream_t stream, std::string &err);
 hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err);
+// runs the paths that render_pass left for its next batch to completion (a no-op when there are none)
+hipError_t render_flush(RenderState &rs, const DeviceGeom &geom, hipStream_t stream, std::string &err);
 hipError_t render_download_film(RenderState &rs, double *out, hipStream_t stream, std::string &err);
 hipError_t render_download_preview(RenderState &rs, int samples_done, double *out, hipStream_t stream, std::string &err);
 void render_free(RenderState &rs);

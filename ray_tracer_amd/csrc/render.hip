@@ -86,6 +86,10 @@ struct Counters {
 	unsigned long long tails;
 	unsigned long long pad;
 };
+#ifndef CARRY_DIVISOR
+#define CARRY_DIVISOR 8
+#endif
+constexpr uint64_t kCarryDivisor = CARRY_DIVISOR; // a batch hands its last paths to the next one once fewer than 1/8 of it are alive (swept at 1080p MIS: 64 -> 2039, 32 -> 2066, 16 -> 2065, 8 -> 2088, 4 -> 2098 spp/s; without 1875)
 constexpr int kMaxBounces = 62; // counter slots per batch; a longer path wraps around (see run_batch)
 // threads per workgroup of the shade kernels.  One slot-reservation atomic per workgroup argues for large groups (a per-wave atomic
 // on one address serialises), turnover argues for small ones: a 1024-thread group is alone on its CU at this register count and the
@@ -134,6 +138,9 @@ struct Impl {
 	Counters *h_counters = nullptr; // pinned mirror, filled by asynchronous copies
 	hipEvent_t ev[kMaxBounces + 2] = {};
 	std::vector<float> film_host;
+	// paths of the previous batch that were still alive when it was cut short (see run_batch): they sit at the front of rays[carry_cur]
+	uint64_t carry_count = 0;
+	int carry_cur = 0;
 	// NaiveBDPT: per-sample records, subpath vertices, connection slot counts and offsets
 	void *bdpt_samples = nullptr, *bdpt_verts = nullptr, *bdpt_scan_tmp = nullptr;
 	uint32_t *bdpt_counts = nullptr, *bdpt_offsets = nullptr;
@@ -489,6 +496,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBan
                                                      uint64_t seed, float tmin, rt_ray *__restrict__ rays,
                                                      PathState *__restrict__ state, BdptSample *__restrict__ samples)
 {
+	// rays and state point at the first free queue slot (paths carried over from the previous batch sit in front of it)
 	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	if (idx >= n_paths) return;
 	const uint64_t npix = (uint64_t)nx * ny;
@@ -1083,6 +1091,7 @@ hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, i
 	}
 	rs.nx = nx; rs.ny = ny; rs.ns = ns; rs.spectral_samples = spectral_samples; rs.algorithm = algorithm; rs.seed = seed;
 	rs.closest_rays = rs.any_rays = rs.camera_samples = 0;
+	im.carry_count = 0; // a new render: paths of an unfinished one are dropped
 	rs.begun = true;
 	return hipStreamSynchronize(stream);
 }
@@ -1106,9 +1115,19 @@ static hipError_t ensure_queues(Impl &im, uint64_t cap, std::string &err)
 }
 
 template <int ALG>
-static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err)
+static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err, bool flush)
 {
-	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_paths = npix * (uint64_t)n_samples;
+	// Late bounces hold few paths (roulette halves them, then kills 90 % per bounce), and a launch over a few thousand rays
+	// costs the latency of one traversal whatever its size: bounces 5 and later were 12 % of a 1080p batch for 1.5 % of its
+	// rays.  A batch therefore stops once the path queue is known to be below 1/kCarryDivisor of the batch; the survivors
+	// stay where they are and the next batch generates its camera rays behind them (a path carries its bounce number, pixel
+	// and random stream, so paths of different depth mix freely).  render_flush runs what is left to completion; everything
+	// that reads the film or the counters calls it first.
+	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_paths = flush ? 0 : npix * (uint64_t)n_samples;
+	const uint64_t carry_limit = (flush || rs.capture_buf) ? 0 : n_paths / kCarryDivisor;
+	const uint64_t carried = im.carry_count;
+	int cur = carried ? im.carry_cur : 0;
+	im.carry_count = 0;
 	const DeviceShade sh = make_shade(im);
 	const float tmin = ALG == RT_ALG_NEE ? 0.0001f : 0.001f; // renderer.cpp:173,235,337
 	Profiler nop, &prof = rs.profiler ? *rs.profiler : nop;
@@ -1121,25 +1140,28 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 		if (rs.capture_count_out) *rs.capture_count_out = rs.capture_count;
 		return e;
 	};
-	prof.begin(Profiler::GENERATE, n_paths, stream);
-	hipLaunchKernelGGL(k_generate<false>, dim3((unsigned)((n_paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands,
-	                   im.n_bands, rs.nx, rs.ny, rs.ns, first_sample, n_paths, rs.seed, tmin, im.rays[0], im.state[0], (BdptSample *)nullptr);
-	prof.end(stream);
-	HIP_TRY(hipGetLastError());
-	rs.camera_samples += n_paths;
+	if (n_paths) {
+		prof.begin(Profiler::GENERATE, n_paths, stream);
+		hipLaunchKernelGGL(k_generate<false>, dim3((unsigned)((n_paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands,
+		                   im.n_bands, rs.nx, rs.ny, rs.ns, first_sample, n_paths, rs.seed, tmin, im.rays[cur] + carried, im.state[cur] + carried,
+		                   (BdptSample *)nullptr);
+		prof.end(stream);
+		HIP_TRY(hipGetLastError());
+		rs.camera_samples += n_paths;
+	}
 	// Queue sizes stay on the device: every kernel of bounce b reads its item count from the slot the previous
 	// kernel wrote, and the host only sizes grids from upper bounds (paths can only die; at most two connection
 	// rays per path).  Counts are copied back asynchronously; the host runs at most two bounces ahead of the
 	// copies and stops as soon as one of them reports an empty path queue.
-	uint64_t entering = n_paths; // paths entering the first bounce of this round of slots
+	uint64_t entering = carried + n_paths; // paths entering the first bounce of this round of slots
 	for (;;) {
 		HIP_TRY(hipMemsetAsync(im.counters, 0, sizeof(Counters) * (kMaxBounces + 2), stream));
 		HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)im.counters, (int)entering, 1, stream));
 		im.h_counters[0].tails = entering;
 		uint64_t bound = entering;
-		int known = 0, b = 0, cur = 0;
+		int known = 0, b = 0;
 		long rec_path[kMaxBounces + 1], rec_conn[kMaxBounces + 1];
-		bool empty = false;
+		bool empty = false, cut = false;
 		for (; b < kMaxBounces; b++) {
 			while (known < b) { // take the counts that have arrived; never run more than two bounces ahead
 				if (b - known > 2 || rs.capture_buf) HIP_TRY(hipEventSynchronize(im.ev[known + 1]));
@@ -1148,6 +1170,7 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 				bound = std::min<uint64_t>(bound, (uint32_t)im.h_counters[known].tails);
 			}
 			if (bound == 0) { empty = true; break; }
+			if (b >= 1 && bound <= carry_limit) { cut = true; break; } // few paths left: they join the next batch
 			const uint32_t *n_path = reinterpret_cast<const uint32_t *>(&im.counters[b]);
 			const uint32_t *n_conn = reinterpret_cast<const uint32_t *>(&im.counters[b + 1]) + 1;
 			if (rs.capture_buf) HIP_TRY(capture(im.rays[cur], bound)); // capture mode is synchronous: bound is exact here
@@ -1204,12 +1227,13 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 			if (rec_conn[k] >= 0) { prof.set_items(rec_conn[k], nc); prof.set_items(rec_conn[k] + 1, nc); }
 		}
 		if (empty) break;
-		entering = (uint32_t)im.h_counters[b].tails; // slots exhausted (a path longer than kMaxBounces): go round again
-		if (entering == 0) break;
-		if (cur != 0) { // the next round reads rays[0]/state[0]: the survivors sit in rays[cur]
-			HIP_TRY(hipMemcpyAsync(im.rays[0], im.rays[cur], entering * sizeof(rt_ray), hipMemcpyDeviceToDevice, stream));
-			HIP_TRY(hipMemcpyAsync(im.state[0], im.state[cur], entering * sizeof(PathState), hipMemcpyDeviceToDevice, stream));
+		entering = (uint32_t)im.h_counters[b].tails; // exact now; the survivors sit at the front of rays[cur]
+		if (cut) {
+			im.carry_count = entering;
+			im.carry_cur = cur;
+			break;
 		}
+		if (entering == 0) break; // otherwise the slots are exhausted (a path longer than kMaxBounces): go round again
 	}
 	return hipSuccess;
 }
@@ -1374,22 +1398,38 @@ hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample
 	uint64_t per_batch = std::max<uint64_t>(1, (1ull << (bdpt ? BDPT_BATCH_LOG2 : 25)) / std::max<uint64_t>(npix, 1));
 	if (npix * per_batch >= (1ull << 31)) per_batch = 1;
 	if (npix >= (1ull << 31)) { err = "image too large for 32-bit path indices"; return hipErrorInvalidValue; }
-	HIP_TRY(ensure_queues(im, npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1)), err));
+	const uint64_t batch_paths = npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1));
+	const uint64_t queue_paths = batch_paths + batch_paths / kCarryDivisor + 1; // room for the paths carried over from the batch before
+	if ((queue_paths > im.capacity || bdpt) && im.carry_count) HIP_TRY(render_flush(rs, geom, stream, err)); // growing frees the queues they sit in
+	HIP_TRY(ensure_queues(im, queue_paths, err));
 	if (bdpt) HIP_TRY(ensure_bdpt(im, npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1)), stream, err));
 	int s = first_sample, end = first_sample + n_samples;
 	while (s < end) {
 		int b = (int)std::min<uint64_t>(per_batch, (uint64_t)(end - s));
 		hipError_t e;
 		switch (rs.algorithm) {
-		case RT_ALG_NAIVE: e = run_batch<RT_ALG_NAIVE>(rs, im, geom, s, b, stream, err); break;
-		case RT_ALG_NEE: e = run_batch<RT_ALG_NEE>(rs, im, geom, s, b, stream, err); break;
+		case RT_ALG_NAIVE: e = run_batch<RT_ALG_NAIVE>(rs, im, geom, s, b, stream, err, false); break;
+		case RT_ALG_NEE: e = run_batch<RT_ALG_NEE>(rs, im, geom, s, b, stream, err, false); break;
 		case RT_ALG_NAIVE_BDPT: e = run_batch_bdpt(rs, im, geom, s, b, stream, err); break;
-		default: e = run_batch<RT_ALG_MIS>(rs, im, geom, s, b, stream, err); break;
+		default: e = run_batch<RT_ALG_MIS>(rs, im, geom, s, b, stream, err, false); break;
 		}
 		if (e != hipSuccess) return e;
 		s += b;
 	}
 	return hipSuccess;
+}
+
+hipError_t render_flush(RenderState &rs, const DeviceGeom &geom, hipStream_t stream, std::string &err)
+{
+	if (!rs.impl || !rs.begun) return hipSuccess;
+	Impl &im = *impl_of(rs);
+	if (im.carry_count == 0) return hipSuccess;
+	switch (rs.algorithm) {
+	case RT_ALG_NAIVE: return run_batch<RT_ALG_NAIVE>(rs, im, geom, 0, 0, stream, err, true);
+	case RT_ALG_NEE: return run_batch<RT_ALG_NEE>(rs, im, geom, 0, 0, stream, err, true);
+	case RT_ALG_MIS: return run_batch<RT_ALG_MIS>(rs, im, geom, 0, 0, stream, err, true);
+	default: im.carry_count = 0; return hipSuccess;
+	}
 }
 
 hipError_t render_download_film(RenderState &rs, double *out, hipStream_t stream, std::string &err)

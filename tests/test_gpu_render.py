@@ -91,6 +91,42 @@ def test_passes_add_up(ctx, cornell_dir):
     assert np.allclose(a, b, rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("alg", [capi.ALG_NAIVE, capi.ALG_NEE, capi.ALG_MIS])
+def test_paths_handed_to_the_next_pass_are_finished(ctx, cornell_dir, alg):
+    """A pass leaves its last few live paths to the next one.  Many small passes must trace exactly the rays of one big
+    pass (same random streams, so the counters agree to the ray) and give its film; the film download, the statistics
+    and the preview finish pending paths by themselves, without rt_render_sync."""
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 96, 64)
+    ctx.upload_mesh(mesh)
+    ctx.upload_materials(records)
+    ctx.set_camera(cam)
+    ctx.render_begin(96, 64, 12, 30, alg, 11)
+    ctx.render_pass(0, 12)
+    ctx.render_sync()
+    one, one_stats = ctx.download_film(), ctx.stats()
+    ctx.render_begin(96, 64, 12, 30, alg, 11)
+    for s in range(12):
+        ctx.render_pass(s, 1)
+    many_stats = ctx.stats()  # no sync before: the counters must already include the pending paths
+    many = ctx.download_film()
+    for k in ("camera_samples", "closest_rays", "any_rays"):
+        assert many_stats[k] == one_stats[k], k
+    assert np.allclose(one, many, rtol=1e-5, atol=1e-9)
+    # two passes of unequal size, read without a sync
+    ctx.render_begin(96, 64, 12, 30, alg, 11)
+    ctx.render_pass(0, 5)
+    ctx.render_pass(5, 7)
+    assert np.allclose(ctx.download_film(), one, rtol=1e-5, atol=1e-9)
+    # a new render drops what an abandoned one left behind
+    ctx.render_begin(96, 64, 12, 30, alg, 11)
+    ctx.render_pass(0, 6)
+    ctx.render_begin(96, 64, 12, 30, alg, 11)
+    ctx.render_pass(0, 12)
+    ctx.render_sync()
+    assert np.allclose(ctx.download_film(), one, rtol=1e-5, atol=1e-9)
+    assert ctx.stats()["closest_rays"] == one_stats["closest_rays"]
+
+
 def test_preview_tonemap(ctx, cornell_dir):
     mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 32, 32)
     ctx.upload_mesh(mesh)
