@@ -202,8 +202,12 @@ int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d
  * will run on); NULL = the context allocates it. */
 int rt_render_begin(rt_context *ctx, int nx, int ny, int ns, int spectral_samples, int algorithm, uint64_t seed, void *d_film);
 /* replaces: passes s = first_sample .. first_sample+n_samples-1 of the loop at renderer.cpp:69-123
- * (camera ray, integrator, film weight, Spectrum::add of rad/ns). Asynchronous on the context's stream. */
+ * (camera ray, integrator, film weight, Spectrum::add of rad/ns).  Work is queued on the context's stream.
+ * A pass may leave the last few of its paths (the deep, nearly empty bounces) for the next pass to carry along;
+ * rt_render_sync, the downloads, rt_get_stats and rt_profile_stop finish them first, so whatever those calls
+ * return accounts for every sample of every pass.  Read the buffer of rt_film_device_ptr after rt_render_sync. */
 int rt_render_pass(rt_context *ctx, int first_sample, int n_samples);
+/* finishes pending paths and waits for the context's stream */
 int rt_render_sync(rt_context *ctx);
 /* replaces: reads of Renderer::spectrum_img (scene.cpp:929): nx*ny*30 doubles, same layout */
 int rt_download_film(rt_context *ctx, double *spectrum_img);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -52,6 +53,8 @@ struct DeviceShade {
 	const uint32_t *tri_leaf;       // fan triangle -> leaf-order index (exact polygon test in NEE)
 	const DevMaterial *materials;
 	const uint32_t *light_faces;
+	int cull_connections;           // 0: trace every connection ray (diagnostic, MI355RT_TRACE_ALL_CONNECTIONS=1)
+	const float4 *light_box;        // per light: (lo.xyz, largest |coordinate|), (hi.xyz, unused): bounding box of the polygon
 	const DevBand *bands;
 	uint32_t n_lights, n_bands;
 	const float *tri_uv;            // 9 floats per fan triangle: vt of its three corners (null: the mesh has none)
@@ -112,6 +115,8 @@ struct Impl {
 	float *face_area = nullptr, *tri_cum = nullptr;
 	DevMaterial *materials = nullptr;
 	uint32_t *light_faces = nullptr;
+	float4 *light_box = nullptr;
+	bool cull_connections = true;
 	DevBand *bands = nullptr;
 	uint32_t n_lights = 0, n_bands = 0;
 	float *tri_uv = nullptr;
@@ -581,6 +586,24 @@ __device__ float environment_radiance(const DeviceShade &sh, const rt_ray &r, in
 // shade: one path vertex.  Emission, light pick and light point, BSDF samples, Russian roulette in
 // the reference's order; appends connection rays and the continuation ray.
 // ---------------------------------------------------------------------------------------------
+// Can the ray (o, d), t >= 0, touch the box of light `sel`?  Used to drop connection rays whose contribution requires
+// the closest hit to lie on that one polygon (renderer.cpp:421): a ray that misses the polygon's box cannot hit the
+// polygon, whatever else it hits, so it is not traced.  The test errs on the side of "yes": the box is widened by 1e-4 of
+// the largest coordinate involved (fp32 slab arithmetic is off by ~1e-7 of it), and comparisons are written so that a NaN
+// (0 * inf on an axis the ray does not move along) accepts.
+__device__ __forceinline__ bool ray_may_reach_box(const DeviceShade &sh, uint32_t sel, f3 o, f3 d)
+{
+	const float4 b0 = sh.light_box[2 * sel], b1 = sh.light_box[2 * sel + 1];
+	const float pad = 1e-4f * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), b0.w)) + 1e-30f;
+	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+	const float x0 = (b0.x - pad - o.x) * ix, x1 = (b1.x + pad - o.x) * ix;
+	const float y0 = (b0.y - pad - o.y) * iy, y1 = (b1.y + pad - o.y) * iy;
+	const float z0 = (b0.z - pad - o.z) * iz, z1 = (b1.z + pad - o.z) * iz;
+	const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+	const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+	return !(tn > tf * 1.00001f) && !(tf < 0.0f);
+}
+
 template <int ALG>
 __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceShade sh, const uint32_t *__restrict__ n_dev, const rt_ray *__restrict__ rays,
                                                   const PathState *__restrict__ state, const rt_hit *__restrict__ hits,
@@ -678,7 +701,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 							c1.c0 = st.beta * ratio * fabsf(gvi.z) * st.weight;
 							c1.c1 = pdfv / fabsf(gvi.z);
 							c1.band_kind = band | (1u << 16);
-							want_c1 = true;
+							want_c1 = !sh.cull_connections || ray_may_reach_box(sh, sel, p, sdir); // counts only if its closest hit is on the chosen light
 						}
 					}
 				}
@@ -875,6 +898,8 @@ DeviceShade make_shade(const Impl &im)
 	sh.tri_leaf = im.tri_leaf;
 	sh.materials = im.materials;
 	sh.light_faces = im.light_faces;
+	sh.light_box = im.light_box;
+	sh.cull_connections = im.cull_connections ? 1 : 0;
 	sh.bands = im.bands;
 	sh.n_lights = im.n_lights;
 	sh.n_bands = im.n_bands;
@@ -1016,7 +1041,6 @@ hipError_t render_upload_material_graphs(RenderState &rs, const rt_material_grap
 hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const std::vector<rt_material> &mats,
                                    const std::vector<uint32_t> &light_faces, hipStream_t stream, std::string &err)
 {
-	(void)host;
 	Impl &im = *impl_of(rs);
 	std::vector<DevMaterial> dm(mats.size());
 	for (size_t i = 0; i < mats.size(); i++) {
@@ -1030,6 +1054,26 @@ hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const
 	free_graphs(im); // new records: programs have to be attached again
 	HIP_TRY(upload(im.light_faces, light_faces, stream));
 	im.n_lights = (uint32_t)light_faces.size();
+	// bounding boxes of the light polygons, rounded outwards to float (see ray_may_reach_box)
+	std::vector<float4> boxes(2 * light_faces.size());
+	for (size_t l = 0; l < light_faces.size(); l++) {
+		const uint32_t f = light_faces[l];
+		double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX}, big = 0.0;
+		for (uint64_t c = host.face_begin[f]; c < host.face_begin[f + 1]; c++)
+			for (int a = 0; a < 3; a++) {
+				lo[a] = std::min(lo[a], host.pv[3 * c + a]);
+				hi[a] = std::max(hi[a], host.pv[3 * c + a]);
+				big = std::max(big, std::fabs(host.pv[3 * c + a]));
+			}
+		float flo[3], fhi[3];
+		for (int a = 0; a < 3; a++) {
+			flo[a] = std::nextafter((float)lo[a], -FLT_MAX);
+			fhi[a] = std::nextafter((float)hi[a], FLT_MAX);
+		}
+		boxes[2 * l] = make_float4(flo[0], flo[1], flo[2], std::nextafter((float)big, FLT_MAX));
+		boxes[2 * l + 1] = make_float4(fhi[0], fhi[1], fhi[2], 0.0f);
+	}
+	HIP_TRY(upload(im.light_box, boxes, stream));
 	return hipSuccess;
 }
 
@@ -1092,6 +1136,10 @@ hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, i
 	rs.nx = nx; rs.ny = ny; rs.ns = ns; rs.spectral_samples = spectral_samples; rs.algorithm = algorithm; rs.seed = seed;
 	rs.closest_rays = rs.any_rays = rs.camera_samples = 0;
 	im.carry_count = 0; // a new render: paths of an unfinished one are dropped
+	{ // diagnostic switch for tests: trace the connection rays that cannot reach their light as well
+		const char *all = std::getenv("MI355RT_TRACE_ALL_CONNECTIONS");
+		im.cull_connections = !(all && all[0] == '1');
+	}
 	rs.begun = true;
 	return hipStreamSynchronize(stream);
 }
@@ -1487,6 +1535,7 @@ void render_free(RenderState &rs)
 		if (im.tri_cum) (void)hipFree(im.tri_cum);
 		if (im.materials) (void)hipFree(im.materials);
 		if (im.light_faces) (void)hipFree(im.light_faces);
+		if (im.light_box) (void)hipFree(im.light_box);
 		if (im.bands) (void)hipFree(im.bands);
 		if (im.env) (void)hipFree(im.env);
 		if (im.tri_uv) (void)hipFree(im.tri_uv);
