@@ -147,7 +147,7 @@ int rt_set_builder(rt_context *ctx, int builder);
 /* Per-hit material graphs.  replaces: the Compute() chains that NodeMaterial::{SampleBSDF,BSDF,PDF,Emitted} run with
  * Argument{rec.vt} on every call (materialnode.cpp:1758-1795) when the albedo / color slot of a Lambertian, ColoredMetal or
  * DiffuseLight node is fed by nodes that read the hit's texture coordinate.  The host compiles such a graph to a postfix
- * program of (op, arg) pairs; values are vectors or spectra, at most four deep:
+ * program of (op, arg) pairs; values are vectors, spectra or scalars, at most six deep:
  *   0 SPEC k     push spectra[k]                      (SpectrumNode and folded constant sub-graphs)
  *   1 VEC k      push vectors[k]                      (RGBColorNode, :931-936)
  *   2 UV         push rec.vt                          (UVNode, :893-896)
@@ -155,7 +155,14 @@ int rt_set_builder(rt_context *ctx, int builder);
  *   5 IMAGE k    uv -> rgb of textures[k]             (ImageTextureNode, :1001-1018)
  *   6 CHECKER k  uv -> (1,1,1) or (0,0,0), size scalars[k]  (CheckerboardNode, :1046-1063)
  *   7 RGB2SPEC   rgb -> spectrum                      (RGBtoSpectrumNode, :949-957)
- *   8 ADD_S, 9 MUL_S, 10 ADD_V, 11 MUL_V              (AdditionNode :1083-1109, MultiplicationNode :1179-1203)
+ *   8 ADD_S, 9 MUL_S, 10 ADD_V, 11 MUL_V              (AdditionNode :1083-1109, MultiplicationNode :1179-1203; 8 and 9 also on two scalars)
+ *   12 ACCESS i  vector -> its component i, a scalar  (AccessVec3ComponentNode, :1293-1301)
+ *   13 COMBINE   three scalars -> vector              (CombineVec3ComponentNode, :1333-1347)
+ *   14 NOISE1 k  scalar -> scalar, scalars[k] = size followed by the size + 1 table values  (ValueNoiseNode, :1366-1384)
+ *   15 NOISE2 k  u, v -> scalar, scalars[k] = u_size, v_size followed by (u_size + 1)(v_size + 1) values, u outermost
+ *                                                     (ValueNoise2DNode, :1447-1478; the tables are drand48 after srand48(323048))
+ *   16 ROTATE    v, n, theta -> v rotated about n     (RodriguesRotationNode, :1536-1573)
+ *   17 SCALAR k  push scalars[k]
  * A program must leave exactly one spectrum.  Call after rt_upload_materials (which drops earlier programs); the record's
  * `a` is ignored for objects that have a program.  graphs == NULL or n_programs == 0 removes all programs. */
 typedef struct rt_texture { const uint8_t *texels; int32_t width, height, bpp; } rt_texture; /* height rows of width texels, bpp >= 3 bytes each */

@@ -1239,7 +1239,12 @@ static double geometry_term(const hitrec *rec0, const hitrec *rec1) /* renderer.
 /* ---- per-hit material graphs: the Compute() chains of materialnode.cpp that read Argument::vt, as a postfix program.
  * Ops (arg): 0 SPEC k  push spectrum k | 1 VEC k  push vector k | 2 UV  push rec.vt (UVNode, :893-896) | 3 ZERO_S | 4 ZERO_V |
  * 5 IMAGE k  uv -> texel rgb (ImageTextureNode, :1001-1018) | 6 CHECKER k  uv -> 0/1 with size scalars[k] (:1046-1063) |
- * 7 RGB2SPEC (spectrum.cpp:219-232) | 8 ADD_S | 9 MUL_S | 10 ADD_V | 11 MUL_V (elementwise, vec3.h:93) */
+ * 7 RGB2SPEC (spectrum.cpp:219-232) | 8 ADD_S | 9 MUL_S | 10 ADD_V | 11 MUL_V (elementwise, vec3.h:93) |
+ * 12 ACCESS i  vector -> its component i (AccessVec3ComponentNode, :1293-1301) | 13 COMBINE  three scalars -> vector (:1333-1347) |
+ * 14 NOISE1 k  scalar -> ValueNoiseNode (:1366-1384), scalars[k] = size, then size + 1 table values |
+ * 15 NOISE2 k  u, v -> ValueNoise2DNode (:1447-1478), scalars[k] = u_size, v_size, then (u_size + 1)(v_size + 1) values |
+ * 16 ROTATE  v, n, theta -> RodriguesRotationNode (:1536-1573) | 17 SCALAR k  push scalars[k].
+ * A scalar sits in s[0] (ADD_S / MUL_S serve scalars too). */
 typedef struct { int is_vec; double s[ORC_NBINS]; v3 v; } gval;
 static void graph_eval(const orc_scene *s, uint32_t begin, uint32_t len, v3 vt, double out[ORC_NBINS])
 {
@@ -1278,10 +1283,64 @@ static void graph_eval(const orc_scene *s, uint32_t begin, uint32_t len, v3 vt, 
 		case 9: for (int i = 0; i < ORC_NBINS; i++) st[sp - 2].s[i] = st[sp - 2].s[i] * st[sp - 1].s[i]; sp--; break;
 		case 10: st[sp - 2].v = vadd(st[sp - 2].v, st[sp - 1].v); sp--; break;
 		case 11: for (int i = 0; i < 3; i++) st[sp - 2].v.e[i] *= st[sp - 1].v.e[i]; sp--; break;
+		case 12: { double c = st[sp - 1].v.e[arg]; st[sp - 1].is_vec = 0; memset(st[sp - 1].s, 0, sizeof(st[sp - 1].s)); st[sp - 1].s[0] = c; break; }
+		case 13: st[sp - 3].v = V(st[sp - 3].s[0], st[sp - 2].s[0], st[sp - 1].s[0]); st[sp - 3].is_vec = 1; sp -= 2; break;
+		case 14: {
+			const double *r = s->g_scalars + arg + 1;
+			int n = (int)s->g_scalars[arg]; /* r has n + 1 entries */
+			double u = fmod(st[sp - 1].s[0], 1.0);
+			if (u < 0.0) u += 1.0;
+			double us = 1.0 / n, rem = fmod(u, us);
+			int x0 = (int)((u - rem) / us), x1 = x0 + 1;
+			if (x1 > n) { x1 = n; if (x0 > n) x0 = n; } /* only reachable through rounding at u -> 1; the reference asserts */
+			double t = rem / us;
+			st[sp - 1].s[0] = (1.0 - t) * r[x0] + t * r[x1];
+			break;
+		}
+		case 15: {
+			unsigned nu = (unsigned)s->g_scalars[arg], nv = (unsigned)s->g_scalars[arg + 1];
+			const double *r = s->g_scalars + arg + 2;
+			double u = fmod(st[sp - 2].s[0], 1.0), v = fmod(st[sp - 1].s[0], 1.0);
+			if (u < 0.0) u += 1.0;
+			if (v < 0.0) v += 1.0;
+			double us = 1.0 / nu, vs = 1.0 / nv, urem = fmod(u, us), vrem = fmod(v, vs);
+			unsigned u0 = (unsigned)((u - urem) / us), v0 = (unsigned)((v - vrem) / vs);
+			if (u0 > nu - 1) u0 = nu - 1; /* as above: the reference would read past its table */
+			if (v0 > nv - 1) v0 = nv - 1;
+			unsigned u1 = u0 + 1, v1 = v0 + 1;
+			double ut = urem / us, vt2 = vrem / vs;
+			ut = ut * ut * (3.0 - 2.0 * ut);
+			vt2 = vt2 * vt2 * (3.0 - 2.0 * vt2);
+			double a = (1.0 - ut) * r[u0 * (nv + 1) + v0] + ut * r[u1 * (nv + 1) + v0];
+			double b = (1.0 - ut) * r[u0 * (nv + 1) + v1] + ut * r[u1 * (nv + 1) + v1];
+			st[sp - 2].s[0] = (1.0 - vt2) * a + vt2 * b;
+			sp--;
+			break;
+		}
+		case 16: {
+			v3 v = st[sp - 3].v, nn = vunit(st[sp - 2].v);
+			double c = cos(st[sp - 1].s[0]), sn = sin(st[sp - 1].s[0]);
+			double nx = nn.e[0], ny = nn.e[1], nz = nn.e[2];
+			v3 r0 = V(c + nx * nx * (1.0 - c), nx * ny * (1.0 - c) - nz * sn, nx * nz * (1.0 - c) + ny * sn);
+			v3 r1 = V(ny * nx * (1.0 - c) + nz * sn, c + ny * ny * (1.0 - c), ny * nz * (1.0 - c) - nx * sn);
+			v3 r2 = V(nz * nx * (1.0 - c) - ny * sn, nz * ny * (1.0 - c) + nx * sn, c + nz * nz * (1.0 - c));
+			st[sp - 3].v = V(vdot(r0, v), vdot(r1, v), vdot(r2, v));
+			sp -= 2;
+			break;
+		}
+		case 17: st[sp].is_vec = 0; memset(st[sp].s, 0, sizeof(st[sp].s)); st[sp].s[0] = s->g_scalars[arg]; sp++; break;
 		default: break;
 		}
 	}
 	memcpy(out, st[0].s, sizeof(double) * ORC_NBINS);
+}
+
+/* slot a of `object` at texture coordinate vt, for tests of the host's graph compiler; 0 when the object has no program */
+int orc_graph_eval(const orc_scene *s, uint32_t object, const double vt[3], double out[ORC_NBINS])
+{
+	if (!s->prog_len || s->prog_len[object] == 0) return 0;
+	graph_eval(s, s->prog_begin[object], s->prog_len[object], V(vt[0], vt[1], vt[2]), out);
+	return 1;
 }
 
 /* the material of a hit; when the object's slot a is a per-hit graph, a copy with that slot evaluated at rec->vt (the copies rotate

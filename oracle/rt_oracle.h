@@ -139,6 +139,8 @@ int orc_scene_set_material_graphs(orc_scene *s, const uint32_t *programs, uint32
                                   const double *spectra, uint32_t n_spectra, const double *vectors, uint32_t n_vectors,
                                   const double *scalars, uint32_t n_scalars, const uint8_t *const *tex, const int *tex_w,
                                   const int *tex_h, const int *tex_bpp, uint32_t n_textures);
+/* slot a of `object` evaluated at texture coordinate vt (returns 0 when the object has no program) */
+int orc_graph_eval(const orc_scene *s, uint32_t object, const double vt[3], double out[ORC_NBINS]);
 /* environment texture of NaivePathTracing (renderer.cpp:175-193; globals of scene.h:20-22); parity unpinned */
 int orc_scene_set_environment(orc_scene *s, const uint8_t *tex, int w, int h, int bpp, double brightness);
 int orc_sphere_hit(const double o[3], const double d[3], double t_min, double t_max, double *t); /* object.cpp:43-75, dome of renderer.cpp:169-171 */

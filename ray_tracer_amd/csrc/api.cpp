@@ -267,8 +267,8 @@ int rt_upload_material_graphs(rt_context *ctx, const rt_material_graphs *g)
 			const int type = ctx->materials[p.object].type;
 			if (type != RT_MAT_LAMBERTIAN && type != RT_MAT_DIFFUSE_LIGHT && type != RT_MAT_COLORED_METAL)
 				return set_err(ctx, RT_ERR_INVALID, "rt_upload_material_graphs: only Lambertian, DiffuseLight and ColoredMetal have a slot fed by a graph");
-			// type-check the program on an abstract stack: 'S' spectrum, 'V' vector
-			char st[4];
+			// type-check the program on an abstract stack: 'S' spectrum, 'V' vector, 'D' scalar
+			char st[6];
 			int sp = 0;
 			auto bad = [&](const char *why) { return set_err(ctx, RT_ERR_INVALID, std::string("rt_upload_material_graphs: ") + why); };
 			for (uint32_t pc = p.code_begin; pc < p.code_begin + p.code_len; pc++) {
@@ -285,12 +285,30 @@ int rt_upload_material_graphs(rt_context *ctx, const rt_material_graphs *g)
 				case 6: if (arg >= g->n_scalars) return bad("scalar index out of range");
 					if (sp < 1 || st[sp - 1] != 'V') return bad("CHECKER needs a vector"); break;
 				case 7: if (sp < 1 || st[sp - 1] != 'V') return bad("RGB2SPEC needs a vector"); st[sp - 1] = 'S'; break;
-				case 8: case 9: if (sp < 2 || st[sp - 1] != 'S' || st[sp - 2] != 'S') return bad("spectrum arithmetic needs two spectra"); sp--; break;
+				case 8: case 9: if (sp < 2 || st[sp - 1] == 'V' || st[sp - 1] != st[sp - 2]) return bad("this arithmetic needs two spectra or two scalars"); sp--; break;
 				case 10: case 11: if (sp < 2 || st[sp - 1] != 'V' || st[sp - 2] != 'V') return bad("vector arithmetic needs two vectors"); sp--; break;
+				case 12: if (arg > 2) return bad("ACCESS index must be 0, 1 or 2");
+					if (sp < 1 || st[sp - 1] != 'V') return bad("ACCESS needs a vector"); st[sp - 1] = 'D'; break;
+				case 13: if (sp < 3 || st[sp - 1] != 'D' || st[sp - 2] != 'D' || st[sp - 3] != 'D') return bad("COMBINE needs three scalars"); sp -= 2; st[sp - 1] = 'V'; break;
+				case 14: { // scalars[arg] = size, then size + 1 table values
+					if (arg >= g->n_scalars) return bad("scalar index out of range");
+					const double n = g->scalars[arg];
+					if (!(n >= 1.0 && n <= 1048576.0) || n != std::floor(n) || (uint64_t)arg + 1 + (uint64_t)n + 1 > g->n_scalars) return bad("NOISE1 table outside the scalar table");
+					if (sp < 1 || st[sp - 1] != 'D') return bad("NOISE1 needs a scalar"); break;
+				}
+				case 15: { // scalars[arg] = u_size, v_size, then (u_size + 1)(v_size + 1) table values
+					if ((uint64_t)arg + 1 >= g->n_scalars) return bad("scalar index out of range");
+					const double nu = g->scalars[arg], nv = g->scalars[arg + 1];
+					if (!(nu >= 1.0 && nu <= 65536.0 && nv >= 1.0 && nv <= 65536.0) || nu != std::floor(nu) || nv != std::floor(nv) ||
+					    (uint64_t)arg + 2 + ((uint64_t)nu + 1) * ((uint64_t)nv + 1) > g->n_scalars) return bad("NOISE2 table outside the scalar table");
+					if (sp < 2 || st[sp - 1] != 'D' || st[sp - 2] != 'D') return bad("NOISE2 needs two scalars"); sp--; break;
+				}
+				case 16: if (sp < 3 || st[sp - 1] != 'D' || st[sp - 2] != 'V' || st[sp - 3] != 'V') return bad("ROTATE needs vector, vector, scalar"); sp -= 2; break;
+				case 17: if (arg >= g->n_scalars) return bad("scalar index out of range"); push = 'D'; break;
 				default: return bad("unknown op");
 				}
 				if (push) {
-					if (sp == 4) return bad("program needs more than four stack entries");
+					if (sp == 6) return bad("program needs more than six stack entries");
 					st[sp++] = push;
 				}
 			}

@@ -219,12 +219,13 @@ __device__ __forceinline__ void film_add(float *film, uint32_t pixel, const DevB
 
 // ---- per-hit material graphs: the Compute() chains of materialnode.cpp that read the hit's texture coordinate, compiled by the
 // host to a postfix program for slot a (albedo / color).  Values are vectors, spectra live in .x (one bin is evaluated at a time).
-// The value stack is four registers deep (rt_upload_material_graphs refuses deeper programs).
-enum { OP_SPEC = 0, OP_VEC, OP_UV, OP_ZERO_S, OP_ZERO_V, OP_IMAGE, OP_CHECKER, OP_RGB2SPEC, OP_ADD_S, OP_MUL_S, OP_ADD_V, OP_MUL_V };
+// The value stack is six registers deep (rt_upload_material_graphs refuses deeper programs).
+enum { OP_SPEC = 0, OP_VEC, OP_UV, OP_ZERO_S, OP_ZERO_V, OP_IMAGE, OP_CHECKER, OP_RGB2SPEC, OP_ADD_S, OP_MUL_S, OP_ADD_V, OP_MUL_V,
+       OP_ACCESS, OP_COMBINE, OP_NOISE1, OP_NOISE2, OP_ROTATE, OP_SCALAR }; // scalars live in .x like spectra (ADD_S / MUL_S serve both)
 
 __device__ float eval_graph(const DeviceShade &sh, uint32_t begin, uint32_t len, f3 uv, int bin)
 {
-	f3 s0 = F3(0, 0, 0), s1 = s0, s2 = s0, s3 = s0; // s0 is the top
+	f3 s0 = F3(0, 0, 0), s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0; // s0 is the top
 	for (uint32_t pc = begin; pc < begin + len; pc++) {
 		const uint2 c = sh.g_code[pc];
 		f3 v = F3(0, 0, 0);
@@ -255,10 +256,57 @@ __device__ float eval_graph(const DeviceShade &sh, uint32_t begin, uint32_t len,
 		case OP_MUL_S: v = F3(s1.x * s0.x, 0, 0); delta = -1; break;
 		case OP_ADD_V: v = s1 + s0; delta = -1; break;
 		case OP_MUL_V: v = F3(s1.x * s0.x, s1.y * s0.y, s1.z * s0.z); delta = -1; break;
+		case OP_ACCESS: v = F3(c.y == 0 ? s0.x : (c.y == 1 ? s0.y : s0.z), 0, 0); break;   // AccessVec3ComponentNode, :1293-1301
+		case OP_COMBINE: v = F3(s2.x, s1.x, s0.x); delta = -2; break;                       // CombineVec3ComponentNode, :1333-1347
+		case OP_SCALAR: v = F3(sh.g_scalars[c.y], 0, 0); delta = 1; break;
+		case OP_NOISE1: { // ValueNoiseNode::Compute, :1366-1384; index arithmetic in double as there
+			const float *r = sh.g_scalars + c.y + 1;
+			const int n = (int)sh.g_scalars[c.y];
+			double u = fmod((double)s0.x, 1.0);
+			if (u < 0.0) u += 1.0;
+			const double us = 1.0 / n, rem = fmod(u, us);
+			int x0 = (int)((u - rem) / us), x1 = x0 + 1;
+			if (x1 > n) { x1 = n; x0 = x0 > n ? n : x0; } // only through rounding at u -> 1 (the reference asserts)
+			const float t = (float)(rem / us);
+			v = F3((1.0f - t) * r[x0] + t * r[x1], 0, 0);
+			break;
+		}
+		case OP_NOISE2: { // ValueNoise2DNode::Compute, :1447-1478
+			const unsigned nu = (unsigned)sh.g_scalars[c.y], nv = (unsigned)sh.g_scalars[c.y + 1];
+			const float *r = sh.g_scalars + c.y + 2;
+			double u = fmod((double)s1.x, 1.0), w = fmod((double)s0.x, 1.0);
+			if (u < 0.0) u += 1.0;
+			if (w < 0.0) w += 1.0;
+			const double us = 1.0 / nu, ws = 1.0 / nv, urem = fmod(u, us), wrem = fmod(w, ws);
+			unsigned u0 = (unsigned)((u - urem) / us), w0 = (unsigned)((w - wrem) / ws);
+			u0 = u0 > nu - 1 ? nu - 1 : u0; // the reference would read past its table
+			w0 = w0 > nv - 1 ? nv - 1 : w0;
+			const unsigned u1 = u0 + 1, w1 = w0 + 1;
+			float ut = (float)(urem / us), wt = (float)(wrem / ws);
+			ut = ut * ut * (3.0f - 2.0f * ut);
+			wt = wt * wt * (3.0f - 2.0f * wt);
+			const float a = (1.0f - ut) * r[u0 * (nv + 1) + w0] + ut * r[u1 * (nv + 1) + w0];
+			const float b = (1.0f - ut) * r[u0 * (nv + 1) + w1] + ut * r[u1 * (nv + 1) + w1];
+			v = F3((1.0f - wt) * a + wt * b, 0, 0);
+			delta = -1;
+			break;
+		}
+		case OP_ROTATE: { // RodriguesRotationNode::Compute, :1536-1573: s2 = v, s1 = n, s0 = theta
+			const f3 nn = unit(s1);
+			float sn, cs;
+			sincosf(s0.x, &sn, &cs);
+			const f3 r0 = F3(cs + nn.x * nn.x * (1.0f - cs), nn.x * nn.y * (1.0f - cs) - nn.z * sn, nn.x * nn.z * (1.0f - cs) + nn.y * sn);
+			const f3 r1 = F3(nn.y * nn.x * (1.0f - cs) + nn.z * sn, cs + nn.y * nn.y * (1.0f - cs), nn.y * nn.z * (1.0f - cs) - nn.x * sn);
+			const f3 r2 = F3(nn.z * nn.x * (1.0f - cs) - nn.y * sn, nn.z * nn.y * (1.0f - cs) + nn.x * sn, cs + nn.z * nn.z * (1.0f - cs));
+			v = F3(dot(r0, s2), dot(r1, s2), dot(r2, s2));
+			delta = -2;
+			break;
+		}
 		default: break;
 		}
-		if (delta > 0) { s3 = s2; s2 = s1; s1 = s0; }
-		else if (delta < 0) { s1 = s2; s2 = s3; }
+		if (delta > 0) { s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; }
+		else if (delta == -1) { s1 = s2; s2 = s3; s3 = s4; s4 = s5; }
+		else if (delta == -2) { s1 = s3; s2 = s4; s3 = s5; }
 		s0 = v;
 	}
 	return s0.x;

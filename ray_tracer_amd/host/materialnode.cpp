@@ -1,4 +1,5 @@
 #include "materialnode.h"
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -111,12 +112,15 @@ std::vector<double> NodeMaterial::SlotSpectrum(int node, const char *slot, const
 
 // ---- per-hit graphs: the same walks as above, but a sub-graph that reads the hit's texture coordinate becomes an expression
 struct NodeMaterial::Expr {
-	char kind = 'S'; // S spectrum constant, V vector constant, U uv, I image, C checker, R rgb->spectrum, + * on spectra, p m on vectors
+	// S spectrum constant, V vector constant, D scalar constant, U uv, I image, C checker, R rgb->spectrum, + * on spectra, p m on vectors,
+	// a s on scalars, A component access, B three scalars -> vector, n 1D noise, N 2D noise, T rotation (a = v, b = n, c = theta)
+	char kind = 'S';
 	std::vector<double> val;
 	double size = 0.0;
+	int nu = 0, nv = 0, index = 0;
 	std::string path;
-	std::shared_ptr<Expr> a, b;
-	bool constant() const { return kind == 'S' || kind == 'V'; }
+	std::shared_ptr<Expr> a, b, c;
+	bool constant() const { return kind == 'S' || kind == 'V' || kind == 'D'; }
 };
 
 namespace {
@@ -185,10 +189,99 @@ std::shared_ptr<NodeMaterial::Expr> NodeMaterial::VecExpr(int node, int depth) c
 		e->b = b;
 		return e;
 	}
-	if (t == "RodriguesRotation" || t == "CombineVec3Component" || t == "ValueNoise" || t == "ValueNoise2D" || t == "AccessVec3Component" ||
-	    t == "RandomSampling")
-		throw UnsupportedMaterialGraph("node " + t + " of material " + name + " is not evaluated on the device");
+	if (t == "CombineVec3Component") { // :1333-1347: stops at the first unconnected input, the rest stays as it was (zero)
+		std::shared_ptr<Expr> part[3];
+		int n = 0;
+		for (const char *slot : {"0", "1", "2"}) {
+			int p = Parent(node, slot);
+			if (p < 0) break;
+			part[n++] = ScalarExpr(p, depth + 1);
+		}
+		if (n == 0) return e;
+		bool all_const = true;
+		for (int i = 0; i < 3; i++) {
+			if (i >= n) { part[i] = std::make_shared<Expr>(); part[i]->kind = 'D'; part[i]->val = {0.0}; }
+			all_const = all_const && part[i]->kind == 'D';
+		}
+		if (all_const) { for (int i = 0; i < 3; i++) e->val[i] = part[i]->val[0]; return e; }
+		e->kind = 'B';
+		e->a = part[0]; e->b = part[1]; e->c = part[2];
+		return e;
+	}
+	if (t == "RodriguesRotation") { // :1536-1573
+		auto nn = std::make_shared<Expr>();
+		nn->kind = 'V';
+		nn->val = {0.0, 0.0, 1.0}; // materialnode.h:423
+		int p = Parent(node, "n");
+		if (p >= 0) nn = VecExpr(p, depth + 1);
+		else if (nodes[node].contains("n")) for (int i = 0; i < 3; i++) nn->val[i] = nodes[node].at("n")[(size_t)i].number(nn->val[i]);
+		auto th = std::make_shared<Expr>();
+		th->kind = 'D';
+		th->val = {nodes[node].contains("theta") ? nodes[node].at("theta").number(0.0) : 0.0};
+		p = Parent(node, "theta");
+		if (p >= 0) th = ScalarExpr(p, depth + 1);
+		p = Parent(node, "v");
+		if (p < 0) return e; // returns before writing
+		e->kind = 'T';
+		e->a = VecExpr(p, depth + 1);
+		e->b = nn;
+		e->c = th;
+		return e;
+	}
 	return e; // no dvec3 Compute: the base class leaves the caller's vector untouched (:81-83)
+}
+
+// Compute(global_arg, double&).  A node without that overload leaves the caller's variable untouched, which the reference's callers
+// never initialise (undefined there); here it reads as 0.
+std::shared_ptr<NodeMaterial::Expr> NodeMaterial::ScalarExpr(int node, int depth) const
+{
+	if (depth > 64) throw UnsupportedMaterialGraph("cyclic material graph in " + name);
+	const std::string t = nodes[node].at("type").string_or("");
+	auto e = std::make_shared<Expr>();
+	e->kind = 'D';
+	e->val = {0.0};
+	if (t == "AccessVec3Component") { // :1293-1301; the index is not stored in the file and stays 0 (materialnode.h:375)
+		int p = Parent(node, "vector");
+		if (p < 0) return e;
+		auto v = VecExpr(p, depth + 1);
+		if (v->kind == 'V') { e->val[0] = v->val[0]; return e; }
+		e->kind = 'A';
+		e->index = 0;
+		e->a = v;
+		return e;
+	}
+	if (t == "ValueNoise") { // :1366-1384
+		int p = Parent(node, "input");
+		if (p < 0) return e;
+		e->kind = 'n';
+		e->nu = (int)nodes[node].at("u_size").number(256.0);
+		e->a = ScalarExpr(p, depth + 1);
+		return e;
+	}
+	if (t == "ValueNoise2D") { // :1447-1478
+		int pu = Parent(node, "u"), pv = Parent(node, "v");
+		if (pu < 0 || pv < 0) return e;
+		e->kind = 'N';
+		e->nu = (int)nodes[node].at("u_size").number(64.0);
+		e->nv = (int)nodes[node].at("v_size").number(64.0);
+		e->a = ScalarExpr(pu, depth + 1);
+		e->b = ScalarExpr(pv, depth + 1);
+		return e;
+	}
+	if (t == "Addition" || t == "Multiplication") { // the double overloads, :1095-1099 and :1192-1195
+		const bool add = t == "Addition";
+		int p0 = Parent(node, "In0"), p1 = Parent(node, "In1");
+		if (p0 < 0) return e;
+		auto a = ScalarExpr(p0, depth + 1);
+		if (p1 < 0) return add ? a : e;
+		auto b = ScalarExpr(p1, depth + 1);
+		if (a->kind == 'D' && b->kind == 'D') { e->val[0] = add ? a->val[0] + b->val[0] : a->val[0] * b->val[0]; return e; }
+		e->kind = add ? 'a' : 's';
+		e->a = a;
+		e->b = b;
+		return e;
+	}
+	return e; // ScalarMultiplication looks up a slot no node has (:1145-1158); RandomSampling writes nothing (:1223-1236)
 }
 
 std::shared_ptr<NodeMaterial::Expr> NodeMaterial::SpecExpr(int node, int depth) const
@@ -274,7 +367,26 @@ bool NodeMaterial::EmitGraph(uint32_t object, MaterialGraphTables &out) const
 			}
 			case 'C': run(*e.a); o.scalars.push_back(e.size); op(6, (uint32_t)(o.scalars.size() - 1)); break;
 			case 'R': run(*e.a); op(7, 0); break;
-			default: run(*e.a); run(*e.b); op(e.kind == '+' ? 8 : e.kind == '*' ? 9 : e.kind == 'p' ? 10 : 11, 0); break;
+			case 'D': o.scalars.push_back(e.val[0]); op(17, (uint32_t)(o.scalars.size() - 1)); break;
+			case 'A': run(*e.a); op(12, (uint32_t)e.index); break;
+			case 'B': run(*e.a); run(*e.b); run(*e.c); op(13, 0); break;
+			case 'n': // ValueNoiseNode::GenerateRand, :1412-1419: srand48(323048), then size + 1 draws
+				run(*e.a);
+				op(14, (uint32_t)o.scalars.size());
+				o.scalars.push_back((double)e.nu);
+				srand48(323048);
+				for (int i = 0; i < e.nu + 1; i++) o.scalars.push_back(drand48());
+				break;
+			case 'N': // ValueNoise2DNode::GenerateRand, :1500-1508
+				run(*e.a); run(*e.b);
+				op(15, (uint32_t)o.scalars.size());
+				o.scalars.push_back((double)e.nu);
+				o.scalars.push_back((double)e.nv);
+				srand48(323048);
+				for (int i = 0; i < (e.nu + 1) * (e.nv + 1); i++) o.scalars.push_back(drand48());
+				break;
+			case 'T': run(*e.a); run(*e.b); run(*e.c); op(16, 0); break;
+			default: run(*e.a); run(*e.b); op(e.kind == '+' || e.kind == 'a' ? 8 : e.kind == '*' || e.kind == 's' ? 9 : e.kind == 'p' ? 10 : 11, 0); break;
 			}
 		}
 	} emit{out};

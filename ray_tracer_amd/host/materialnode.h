@@ -50,6 +50,7 @@ private:
 	std::vector<double> SlotSpectrum(int node, const char *slot, const char *own_key) const;
 	struct Expr;
 	std::shared_ptr<Expr> VecExpr(int node, int depth) const;
+	std::shared_ptr<Expr> ScalarExpr(int node, int depth) const;
 	std::shared_ptr<Expr> SpecExpr(int node, int depth) const;
 	std::shared_ptr<Expr> SlotExpr(void) const; // the expression of the BSDF node's albedo / color slot, null for other nodes
 };

@@ -1,7 +1,7 @@
 // Headless driver for the host-side Renderer: what the reference's `--cli` mode does (main.cpp:54-99) plus the
 // camera set-up the GUI performs (scene.cpp:866-867), with the linear film dumped for tests.
 //   rt_cli --obj scene.obj --materials materials.json --objmatmap map.json [--width W --height H --sample S]
-//          [--algorithm naive|nee|mis|bdpt|misbdpt] [--seed N] [--spectral 30] [--film out.f64] [--ppm out.ppm] [--records out.f64]
+//          [--algorithm naive|nee|mis|bdpt|misbdpt] [--seed N] [--spectral 30] [--film out.f64] [--ppm out.ppm] [--records out.f64] [--graphs out.bin]
 //          [--ply mesh.ply --ply-object NAME --ply-normals auto|file|flat|smooth]   one more object from a PLY file
 //   rt_cli --ply mesh.ply --dump-ply out.bin       host only: the parsed tables (u64 nv, nf, ni, has_normals; f64 [nv][6];
 //                                                  u64 [nf+1]; i32 [ni]) for tests
@@ -16,7 +16,7 @@ using namespace mi355host;
 
 int main(int argc, char **argv)
 {
-	std::string objp, matp, mapp, film_out, ppm_out, rec_out, alg = "mis", plyp, ply_object = "ply", ply_normals = "auto", ply_dump;
+	std::string objp, matp, mapp, film_out, ppm_out, rec_out, graphs_out, alg = "mis", plyp, ply_object = "ply", ply_normals = "auto", ply_dump;
 	int w = 64, h = 64, ns = 4, spectral = 30;
 	unsigned long long seed = 1;
 	for (int i = 1; i + 1 < argc; i += 2) {
@@ -25,7 +25,7 @@ int main(int argc, char **argv)
 		else if (k == "--width") w = std::atoi(v.c_str()); else if (k == "--height") h = std::atoi(v.c_str());
 		else if (k == "--sample") ns = std::atoi(v.c_str()); else if (k == "--algorithm") alg = v;
 		else if (k == "--seed") seed = std::strtoull(v.c_str(), nullptr, 10); else if (k == "--spectral") spectral = std::atoi(v.c_str());
-		else if (k == "--film") film_out = v; else if (k == "--ppm") ppm_out = v; else if (k == "--records") rec_out = v;
+		else if (k == "--film") film_out = v; else if (k == "--ppm") ppm_out = v; else if (k == "--records") rec_out = v; else if (k == "--graphs") graphs_out = v;
 		else if (k == "--ply") plyp = v; else if (k == "--ply-object") ply_object = v; else if (k == "--ply-normals") ply_normals = v;
 		else if (k == "--dump-ply") ply_dump = v;
 		else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
@@ -62,6 +62,22 @@ int main(int argc, char **argv)
 				f.write((const char *)m.a, sizeof(m.a));
 				f.write((const char *)m.b, sizeof(m.b));
 			}
+		}
+		if (!graphs_out.empty()) { // host logic only: the per-hit programs, as u64 counts (programs, code pairs, spectra, vectors, scalars),
+			// then u32 [programs][3], u32 [pairs][2], f64 spectra, vectors, scalars
+			obj parsed;
+			parsed.Load(objp.c_str());
+			MaterialGraphTables t;
+			uint32_t k = 0;
+			for (auto *o : parsed.objects) by_object.at(o->name)->EmitGraph(k++, t);
+			std::ofstream f(graphs_out, std::ios::binary);
+			uint64_t head[5] = {t.programs.size(), t.code.size() / 2, t.spectra.size() / 30, t.vectors.size() / 3, t.scalars.size()};
+			f.write((const char *)head, sizeof(head));
+			f.write((const char *)t.programs.data(), sizeof(rt_graph_program) * t.programs.size());
+			f.write((const char *)t.code.data(), sizeof(uint32_t) * t.code.size());
+			f.write((const char *)t.spectra.data(), sizeof(double) * t.spectra.size());
+			f.write((const char *)t.vectors.data(), sizeof(double) * t.vectors.size());
+			f.write((const char *)t.scalars.data(), sizeof(double) * t.scalars.size());
 		}
 		Renderer r;
 		if (!r.last_error.empty()) return 3;

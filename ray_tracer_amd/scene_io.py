@@ -459,8 +459,8 @@ def write_ply(path, vertices, faces, normals=None, binary=False):
 # material node graphs (materialnode.cpp)
 # ----------------------------------------------------------------------------------------------
 class UnsupportedMaterialGraph(ValueError):
-    """The graph uses a node that is not evaluated on the device (noise, rotation, component access) or one the
-    reference leaves undefined (GGX)."""
+    """The graph cannot be turned into a material record: a node the reference leaves undefined (GGX), a cycle, a texture
+    file in a format that is not decoded here."""
 
 
 def rgb_to_spectrum(rgb):  # spectrum.cpp:219-232
@@ -546,7 +546,8 @@ class NodeMaterial:
 
     # ---- per-hit graphs: the same walks, but a sub-graph that reads the hit's texture coordinate becomes an expression
     # ("S", spectrum) | ("V", vec3) constants; ("UV",); ("IMG", texels, uv); ("CHK", size, uv); ("R2S", vec);
-    # ("ADDS" | "MULS", a, b) on spectra; ("ADDV" | "MULV", a, b) on vectors
+    # ("ADDS" | "MULS", a, b) on spectra; ("ADDV" | "MULV", a, b) on vectors; scalars: ("D", x) constants, ("ACC", i, vec),
+    # ("N1", size, x), ("N2", u_size, v_size, u, v), ("ADDD" | "MULD", a, b); vectors from scalars: ("CMB", a, b, c), ("ROT", v, n, theta)
     def _texture(self, path):
         """texels of an ImageTexture node as uint8 [h, w, bpp], or None when there is no readable file (the reference then leaves
         its output untouched, materialnode.cpp:1003-1004).  The reference decodes with stb_image; here: a dict handed to the
@@ -608,9 +609,76 @@ class NodeMaterial:
             if a[0] == "V" and b[0] == "V":
                 return ("V", a[1] + b[1] if t == "Addition" else a[1] * b[1])
             return ("ADDV" if t == "Addition" else "MULV", a, b)
-        if t in ("RodriguesRotation", "CombineVec3Component", "ValueNoise", "ValueNoise2D", "AccessVec3Component", "RandomSampling"):
-            raise UnsupportedMaterialGraph("node %s of material %s is not evaluated on the device" % (t, self.name))
+        if t == "CombineVec3Component":  # :1333-1347: stops at the first unconnected input, the rest stays as it was (zero)
+            parts = []
+            for slot in ("0", "1", "2"):
+                p = self._parent(node_i, slot)
+                if p is None:
+                    break
+                parts.append(self._scalar_expr(p, depth + 1))
+            if not parts:
+                return zero
+            parts += [("D", 0.0)] * (3 - len(parts))
+            if all(e[0] == "D" for e in parts):
+                return ("V", np.array([e[1] for e in parts]))
+            return ("CMB",) + tuple(parts)
+        if t == "RodriguesRotation":  # :1536-1573
+            p = self._parent(node_i, "n")
+            n = ("V", np.asarray(node.get("n", [0.0, 0.0, 1.0]), dtype=np.float64)) if p is None else self._vec_expr(p, depth + 1)
+            p = self._parent(node_i, "theta")
+            theta = ("D", float(node.get("theta", 0.0))) if p is None else self._scalar_expr(p, depth + 1)
+            p = self._parent(node_i, "v")
+            if p is None:
+                return zero  # returns before writing
+            return ("ROT", self._vec_expr(p, depth + 1), n, theta)
         return zero  # no dvec3 Compute: the base class leaves the caller's vector untouched (:81-83)
+
+    @staticmethod
+    def noise_table(count, seed=323048):
+        """ValueNoiseNode::GenerateRand / ValueNoise2DNode::GenerateRand (:1412-1419, :1500-1508): srand48(seed), then drand48()
+        per entry (the default seed of materialnode.h:395,408; nothing in a materials file changes it)"""
+        import ctypes
+        libc = ctypes.CDLL(None)
+        libc.drand48.restype = ctypes.c_double
+        libc.srand48(ctypes.c_long(seed))
+        return np.array([libc.drand48() for _ in range(count)])
+
+    def _scalar_expr(self, node_i, depth=0):
+        """Compute(global_arg, double&).  A node without that overload leaves the caller's variable untouched, which the
+        reference's callers never initialise (undefined there); here it reads as 0."""
+        if depth > 64:
+            raise UnsupportedMaterialGraph("cyclic material graph in %s" % self.name)
+        node = self.nodes[node_i]
+        t = node["type"]
+        zero = ("D", 0.0)
+        if t == "AccessVec3Component":  # :1293-1301; the index is not stored in the file and stays 0 (materialnode.h:375)
+            p = self._parent(node_i, "vector")
+            if p is None:
+                return zero
+            v = self._vec_expr(p, depth + 1)
+            return ("D", float(v[1][0])) if v[0] == "V" else ("ACC", 0, v)
+        if t == "ValueNoise":  # :1366-1384
+            p = self._parent(node_i, "input")
+            if p is None:
+                return zero
+            return ("N1", int(node["u_size"]), self._scalar_expr(p, depth + 1))
+        if t == "ValueNoise2D":  # :1447-1478
+            pu, pv = self._parent(node_i, "u"), self._parent(node_i, "v")
+            if pu is None or pv is None:
+                return zero
+            return ("N2", int(node["u_size"]), int(node["v_size"]), self._scalar_expr(pu, depth + 1), self._scalar_expr(pv, depth + 1))
+        if t in ("Addition", "Multiplication"):  # the double overloads, :1095-1099 and :1192-1195
+            p0, p1 = self._parent(node_i, "In0"), self._parent(node_i, "In1")
+            if p0 is None:
+                return zero
+            a = self._scalar_expr(p0, depth + 1)
+            if p1 is None:
+                return a if t == "Addition" else zero
+            b = self._scalar_expr(p1, depth + 1)
+            if a[0] == "D" and b[0] == "D":
+                return ("D", a[1] + b[1] if t == "Addition" else a[1] * b[1])
+            return ("ADDD" if t == "Addition" else "MULD", a, b)
+        return zero  # ScalarMultiplication looks up a slot no node has (:1145-1158); RandomSampling writes nothing (:1223-1236)
 
     def _spec_expr(self, node_i, depth=0):
         if depth > 64:
@@ -687,7 +755,8 @@ class NodeMaterial:
         return rec
 
 
-OP_SPEC, OP_VEC, OP_UV, OP_ZERO_S, OP_ZERO_V, OP_IMAGE, OP_CHECKER, OP_RGB2SPEC, OP_ADD_S, OP_MUL_S, OP_ADD_V, OP_MUL_V = range(12)
+(OP_SPEC, OP_VEC, OP_UV, OP_ZERO_S, OP_ZERO_V, OP_IMAGE, OP_CHECKER, OP_RGB2SPEC, OP_ADD_S, OP_MUL_S, OP_ADD_V, OP_MUL_V,
+ OP_ACCESS, OP_COMBINE, OP_NOISE1, OP_NOISE2, OP_ROTATE, OP_SCALAR) = range(18)
 
 
 def compile_material_graphs(records):
@@ -716,9 +785,25 @@ def compile_material_graphs(records):
             emit(e[2]); scalars.append(e[1]); code.append((OP_CHECKER, len(scalars) - 1))
         elif k == "R2S":
             emit(e[1]); code.append((OP_RGB2SPEC, 0))
+        elif k == "D":
+            scalars.append(float(e[1])); code.append((OP_SCALAR, len(scalars) - 1))
+        elif k == "ACC":
+            emit(e[2]); code.append((OP_ACCESS, e[1]))
+        elif k == "CMB":
+            emit(e[1]); emit(e[2]); emit(e[3]); code.append((OP_COMBINE, 0))
+        elif k == "N1":
+            emit(e[2])
+            code.append((OP_NOISE1, len(scalars)))
+            scalars.extend([float(e[1])] + list(NodeMaterial.noise_table(e[1] + 1)))
+        elif k == "N2":
+            emit(e[3]); emit(e[4])
+            code.append((OP_NOISE2, len(scalars)))
+            scalars.extend([float(e[1]), float(e[2])] + list(NodeMaterial.noise_table((e[1] + 1) * (e[2] + 1))))
+        elif k == "ROT":
+            emit(e[1]); emit(e[2]); emit(e[3]); code.append((OP_ROTATE, 0))
         else:
             emit(e[1]); emit(e[2])
-            code.append(({"ADDS": OP_ADD_S, "MULS": OP_MUL_S, "ADDV": OP_ADD_V, "MULV": OP_MUL_V}[k], 0))
+            code.append(({"ADDS": OP_ADD_S, "MULS": OP_MUL_S, "ADDV": OP_ADD_V, "MULV": OP_MUL_V, "ADDD": OP_ADD_S, "MULD": OP_MUL_S}[k], 0))
 
     for obj, r in enumerate(records):
         if r.get("graph") is None:

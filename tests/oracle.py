@@ -208,6 +208,14 @@ class Scene:
                                                _p(g["spectra"]), len(g["spectra"]), _p(g["vectors"]), len(g["vectors"]),
                                                _p(g["scalars"]), len(g["scalars"]), ptrs, w, h, bpp, n)
 
+    def graph_eval(self, obj, vt):
+        """slot a of object `obj` at texture coordinate vt (30 bins), or None when the object has no per-hit program"""
+        L = lib()
+        L.orc_graph_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        vt = np.ascontiguousarray(vt, dtype=np.float64)
+        out = np.zeros(NBINS)
+        return out if L.orc_graph_eval(self.h, obj, _p(vt), _p(out)) else None
+
     def set_environment(self, texels, brightness=0.5):
         L = lib()
         L.orc_scene_set_environment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]

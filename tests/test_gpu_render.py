@@ -340,17 +340,40 @@ def graph_records(mesh, records):
                      {"output_node": 6, "output_slot": "Out->", "input_node": 3, "input_slot": "In1"},
                      {"output_node": 5, "output_slot": "Out", "input_node": 4, "input_slot": "RGB"},
                      {"output_node": 0, "output_slot": "Out->", "input_node": 5, "input_slot": "UV"}], light=True, textures={"l": tex_l}).record()
-    assert all("graph" in r for r in (checker, image, lamp))
+    # procedural colour: r = noise1(u), g = noise2(u, rot.x), b = noise1(u + rot.x) with rot = the texture coordinate scaled by a
+    # colour and rotated about (1, 2, 3) (AccessVec3Component, ValueNoise, ValueNoise2D, CombineVec3Component, RodriguesRotation,
+    # scalar Addition, vector Multiplication); connection order matters where a slot name is a prefix of another (see test_host)
+    def c(out, inn, slot):
+        return {"output_node": out, "output_slot": "o", "input_node": inn, "input_slot": slot}
+    noise = material({"type": "Lambertian", "name": "l", "albedo": [0.0] * 30}, "albedo",
+                     [{"type": "RGBtoSpectrum"},                                      # 3
+                      {"type": "CombineVec3Component"},                               # 4
+                      {"type": "ValueNoise", "u_size": 9},                            # 5  r
+                      {"type": "ValueNoise2D", "u_size": 6, "v_size": 4},             # 6  g
+                      {"type": "ValueNoise", "u_size": 5},                            # 7  b
+                      {"type": "Addition"},                                           # 8  u + rot.x
+                      {"type": "AccessVec3Component"},                                # 9  u
+                      {"type": "AccessVec3Component"},                                # 10 rot.x
+                      {"type": "RodriguesRotation", "n": [1.0, 2.0, 3.0], "theta": 0.7},  # 11
+                      {"type": "Multiplication"},                                     # 12 uv * colour
+                      {"type": "RGBColor", "col": [3.0, -2.0, 1.0]}],                 # 13
+                     [c(4, 3, "RGB"), c(5, 4, "0"), c(6, 4, "1"), c(7, 4, "2"),
+                      c(9, 5, "input"), c(9, 6, "u"), c(10, 6, "v"), c(8, 7, "input"),
+                      c(9, 8, "In0"), c(10, 8, "In1"),
+                      c(0, 9, "vector"),
+                      c(12, 11, "v"), c(11, 10, "vector"),
+                      c(0, 12, "In0"), c(13, 12, "In1")]).record()
+    assert all("graph" in r for r in (checker, image, lamp, noise))
     recs = [dict(r) for r in records]
     plain = [i for i, r in enumerate(recs) if not r["light_flag"]]
     lights = [i for i, r in enumerate(recs) if r["light_flag"]]
-    recs[plain[0]], recs[plain[1]], recs[lights[0]] = checker, image, lamp
+    recs[plain[0]], recs[plain[1]], recs[plain[2]], recs[lights[0]] = checker, image, noise, lamp
     return recs
 
 
 @pytest.mark.parametrize("alg", [capi.ALG_NAIVE, capi.ALG_NEE, capi.ALG_MIS, capi.ALG_NAIVE_BDPT])
 def test_per_hit_material_graphs_match_oracle(ctx, cornell_dir, alg):
-    """Checkerboard, ImageTexture, RGBtoSpectrum, Addition and Multiplication evaluated at the hit's texture coordinate (rec.vt,
+    """Checkerboard, ImageTexture, RGBtoSpectrum, Addition, Multiplication and the noise / rotation / component nodes evaluated at the hit's texture coordinate (rec.vt,
     object.cpp:258) for albedo and for a light's colour, through every integrator; same random streams on both sides"""
     mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 48, 36)
     assert len(mesh["vt"]) > 0 and (mesh["corners"][:, 1] >= 0).all()
@@ -399,7 +422,11 @@ def test_material_graph_programs_are_validated(ctx, cornell_dir):
     assert upload([(2, 0)]) != capi.OK                                     # leaves a vector
     assert upload([(0, 0), (0, 0)]) != capi.OK                             # leaves two values
     assert upload([(8, 0)]) != capi.OK                                     # arithmetic on an empty stack
-    assert upload([(0, 0)] * 5 + [(8, 0)] * 4) != capi.OK                  # deeper than four
+    assert upload([(0, 0)] * 7 + [(8, 0)] * 6) != capi.OK                  # deeper than six
+    assert upload([(0, 0)] * 6 + [(8, 0)] * 5) == capi.OK
+    assert upload([(2, 0), (12, 0), (17, 0), (8, 0)]) != capi.OK           # leaves a scalar
+    assert upload([(2, 0), (12, 3)]) != capi.OK                            # component 3 of a vector
+    assert upload([(17, 0), (14, 0)]) != capi.OK                           # noise table outside the scalar table
     assert upload([(99, 0)]) != capi.OK                                    # unknown op
     assert upload([(0, 0), (0, 0), (9, 0)]) == capi.OK
 

@@ -87,8 +87,12 @@ def test_material_folding(cornell_dir):
     g = scene_io.compile_material_graphs([flat, rec])
     assert g["programs"].tolist() == [[1, 0, 3]] and g["code"].tolist() == [[scene_io.OP_UV, 0], [scene_io.OP_IMAGE, 0], [scene_io.OP_RGB2SPEC, 0]]
     assert scene_io.compile_material_graphs([flat]) is None
-    # nodes that are not evaluated on the device are refused, not silently flattened
-    tex["nodes"][4] = {"type": "ValueNoise"}
+    # ValueNoise has no vector Compute: wired to an RGB input it leaves the vector untouched, and the albedo folds to zero
+    tex["nodes"][4] = {"type": "ValueNoise", "u_size": 4}
+    flat = scene_io.NodeMaterial(tex).record()
+    assert "graph" not in flat and not flat["a"].any()
+    # a BSDF the reference leaves undefined is refused, not silently flattened
+    tex["nodes"][2] = {"type": "GGXReflection"}
     with pytest.raises(scene_io.UnsupportedMaterialGraph):
         scene_io.NodeMaterial(tex).record()
     # Dielectric: the "surface_color" lookup never matches the slot "surface color" -> own array
@@ -148,3 +152,195 @@ def test_cpp_host_folds_materials_like_the_python_host(cornell_dir, tmp_path):
     for g, r in zip(got, records):
         assert int(g[0]) == r["type"] and bool(g[1]) == r["light_flag"]
         assert np.array_equal(g[2:32], r["a"]) and np.array_equal(g[32:62], r["b"])
+
+
+def _walk(mat, uv):
+    """The reference's Compute() recursion written out directly (materialnode.cpp), independent of the host's compiler:
+    returns slot `albedo` of the Lambertian behind the output node at texture coordinate uv."""
+    nodes, parent = mat.nodes, mat._parent
+
+    def scal(i):
+        n, t = nodes[i], nodes[i]["type"]
+        if t == "AccessVec3Component":
+            p = parent(i, "vector")
+            return 0.0 if p is None else vec(p)[0]
+        if t == "ValueNoise":
+            p = parent(i, "input")
+            if p is None:
+                return 0.0
+            r = scene_io.NodeMaterial.noise_table(n["u_size"] + 1)
+            u = np.fmod(scal(p), 1.0)
+            u = u + 1.0 if u < 0.0 else u
+            us = 1.0 / (len(r) - 1)
+            rem = np.fmod(u, us)
+            x0 = int((u - rem) / us)
+            t_ = rem / us
+            return (1.0 - t_) * r[x0] + t_ * r[x0 + 1]
+        if t == "ValueNoise2D":
+            pu, pv = parent(i, "u"), parent(i, "v")
+            if pu is None or pv is None:
+                return 0.0
+            nu, nv = n["u_size"], n["v_size"]
+            r = scene_io.NodeMaterial.noise_table((nu + 1) * (nv + 1))
+            u, v = np.fmod(scal(pu), 1.0), np.fmod(scal(pv), 1.0)
+            u = u + 1.0 if u < 0.0 else u
+            v = v + 1.0 if v < 0.0 else v
+            us, vs = 1.0 / nu, 1.0 / nv
+            urem, vrem = np.fmod(u, us), np.fmod(v, vs)
+            u0, v0 = int((u - urem) / us), int((v - vrem) / vs)
+            ut, vt = urem / us, vrem / vs
+            ut, vt = ut * ut * (3.0 - 2.0 * ut), vt * vt * (3.0 - 2.0 * vt)
+            a = (1.0 - ut) * r[u0 * (nv + 1) + v0] + ut * r[(u0 + 1) * (nv + 1) + v0]
+            b = (1.0 - ut) * r[u0 * (nv + 1) + v0 + 1] + ut * r[(u0 + 1) * (nv + 1) + v0 + 1]
+            return (1.0 - vt) * a + vt * b
+        if t in ("Addition", "Multiplication"):
+            p0, p1 = parent(i, "In0"), parent(i, "In1")
+            if p0 is None:
+                return 0.0
+            a = scal(p0)
+            if p1 is None:
+                return a if t == "Addition" else 0.0
+            return a + scal(p1) if t == "Addition" else a * scal(p1)
+        return 0.0
+
+    def vec(i):
+        n, t = nodes[i], nodes[i]["type"]
+        if t == "UV":
+            return np.asarray(uv, dtype=np.float64)
+        if t == "RGBColor":
+            return np.asarray(n["col"], dtype=np.float64)
+        if t == "CombineVec3Component":
+            out = np.zeros(3)
+            for k, slot in enumerate(("0", "1", "2")):
+                p = parent(i, slot)
+                if p is None:
+                    break
+                out[k] = scal(p)
+            return out
+        if t == "RodriguesRotation":
+            p = parent(i, "n")
+            nn = np.asarray(n.get("n", [0, 0, 1]), dtype=np.float64) if p is None else vec(p)
+            nn = nn / np.sqrt((nn * nn).sum())
+            p = parent(i, "theta")
+            th = n.get("theta", 0.0) if p is None else scal(p)
+            c, s_ = np.cos(th), np.sin(th)
+            p = parent(i, "v")
+            if p is None:
+                return np.zeros(3)
+            x, y, z = nn
+            rot = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s_, x * z * (1 - c) + y * s_],
+                            [y * x * (1 - c) + z * s_, c + y * y * (1 - c), y * z * (1 - c) - x * s_],
+                            [z * x * (1 - c) - y * s_, z * y * (1 - c) + x * s_, c + z * z * (1 - c)]])
+            return rot @ vec(p)
+        if t in ("Addition", "Multiplication"):
+            p0, p1 = parent(i, "In0"), parent(i, "In1")
+            if p0 is None:
+                return np.zeros(3)
+            a = vec(p0)
+            if p1 is None:
+                return a if t == "Addition" else np.zeros(3)
+            return a + vec(p1) if t == "Addition" else a * vec(p1)
+        return np.zeros(3)
+
+    def spec(i):
+        n, t = nodes[i], nodes[i]["type"]
+        if t == "Spectrum":
+            return np.asarray(n["data"], dtype=np.float64)
+        if t == "RGBtoSpectrum":
+            p = parent(i, "RGB")
+            return np.zeros(30) if p is None else scene_io.rgb_to_spectrum(vec(p))
+        if t in ("Addition", "Multiplication"):
+            p0, p1 = parent(i, "In0"), parent(i, "In1")
+            if p0 is None:
+                return np.zeros(30)
+            a = spec(p0)
+            if p1 is None:
+                return a if t == "Addition" else np.zeros(30)
+            return a + spec(p1) if t == "Addition" else a * spec(p1)
+        return np.zeros(30)
+
+    bsdf = parent(1, "BSDF")
+    return spec(parent(bsdf, "albedo"))
+
+
+def noise_material(name="noisy"):
+    """UV -> rotate about (1, 2, 3) by 0.7 -> components -> 1D noise, 2D noise and a sum -> vector -> RGBtoSpectrum, times a
+    spectrum: every scalar and vector node of materialnode.cpp that reads the texture coordinate"""
+    nodes = [{"type": "UV"}, {"type": "Output"}, {"type": "Lambertian", "albedo": [1] * 30},
+             {"type": "Multiplication"}, {"type": "Spectrum", "data": list(np.linspace(0.5, 1.0, 30))}, {"type": "RGBtoSpectrum"},
+             {"type": "CombineVec3Component"},
+             {"type": "ValueNoise", "u_size": 7}, {"type": "ValueNoise2D", "u_size": 5, "v_size": 3}, {"type": "Addition"},
+             {"type": "AccessVec3Component"}, {"type": "AccessVec3Component"},
+             {"type": "RodriguesRotation", "n": [1.0, 2.0, 3.0], "theta": 0.7},
+             {"type": "Multiplication"}, {"type": "RGBColor", "col": [3.0, -2.0, 1.0]}]
+    def c(out, inn, slot):
+        return {"output_node": out, "output_slot": "o", "input_node": inn, "input_slot": slot}
+    conns = [c(2, 1, "BSDF"), c(3, 2, "albedo"), c(4, 3, "In0"), c(5, 3, "In1"), c(6, 5, "RGB"),
+             c(7, 6, "0"), c(8, 6, "1"), c(9, 6, "2"),
+             c(10, 7, "input"),           # noise1(uv.x)
+             c(10, 8, "u"), c(11, 8, "v"),  # noise2(uv.x, rotated.x)
+             c(7, 9, "In0"), c(11, 9, "In1"),  # noise1 + rotated.x
+             c(13, 12, "v"),              # rotate (uv * colour); listed before the rotation's outgoing link into a slot named
+                                          # "vector": GetInputParentNode("v") takes the first link whose slot starts with "v"
+             c(0, 10, "vector"), c(12, 11, "vector"),
+             c(0, 13, "In0"), c(14, 13, "In1")]
+    return {"name": name, "nodes": nodes, "connections": conns}
+
+
+def test_noise_rotation_and_component_nodes_compile_to_what_the_reference_computes(cornell_dir):
+    """host compiler + the checker's program evaluation against the direct recursion, at random texture coordinates
+    (negative and > 1 included: the noise nodes wrap them)"""
+    import oracle
+    mat = scene_io.NodeMaterial(noise_material())
+    rec = mat.record()
+    assert rec["type"] == capi.MAT_LAMBERTIAN and "graph" in rec
+    g = scene_io.compile_material_graphs([rec])
+    ops = set(g["code"][:, 0].tolist())
+    assert {scene_io.OP_ACCESS, scene_io.OP_COMBINE, scene_io.OP_NOISE1, scene_io.OP_NOISE2, scene_io.OP_ROTATE} <= ops
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 8, 8)
+    sc = oracle.Scene(mesh)
+    recs = [dict(r) for r in records]
+    plain = [i for i, r in enumerate(records) if not r["light_flag"]][0]
+    recs[plain] = rec
+    assert sc.set_materials(recs) == 1
+    rng = np.random.default_rng(12)
+    for uv in np.concatenate([rng.random((200, 3)), rng.uniform(-3, 3, (100, 3))]):
+        got = sc.graph_eval(plain, uv)
+        want = _walk(mat, uv)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-14), (uv, got[:3], want[:3])
+    assert sc.graph_eval(plain + 1 if plain + 1 < len(recs) else plain - 1, [0.5, 0.5, 0]) is None
+
+
+def test_cpp_host_compiles_noise_graphs_like_the_python_host(cornell_dir, tmp_path):
+    """the same materials file through rt_cli --graphs (host logic only, runs without a device) and through scene_io: identical
+    programs and tables, noise tables (srand48 / drand48) included"""
+    import json
+    import subprocess
+    mats = json.load(open(os.path.join(cornell_dir, "materials.json")))
+    noisy = noise_material("white")
+    for n in noisy["nodes"]:
+        n.setdefault("name", n["type"]); n.setdefault("input_slots", []); n.setdefault("output_slots", []); n.setdefault("pos", {"x": 0, "y": 0})
+    mats = [noisy if m["name"] == "white" else m for m in mats]
+    mpath = tmp_path / "materials.json"
+    mpath.write_text(json.dumps(mats))
+    cli = os.path.join(ROOT, "ray_tracer_amd", "lib", "rt_cli")
+    out = tmp_path / "graphs.bin"
+    subprocess.run([cli, "--obj", os.path.join(cornell_dir, "cornell_box_triangulated.obj"), "--materials", str(mpath), "--objmatmap",
+                    os.path.join(cornell_dir, "objmatmap.json"), "--graphs", str(out)], capture_output=True, text=True, timeout=120)
+    raw = out.read_bytes()
+    head = np.frombuffer(raw, dtype=np.uint64, count=5)
+    off = 40
+    def take(dtype, count):
+        nonlocal off
+        a = np.frombuffer(raw, dtype=dtype, count=int(count), offset=off)
+        off += a.nbytes
+        return a
+    progs, code = take(np.uint32, head[0] * 3).reshape(-1, 3), take(np.uint32, head[1] * 2).reshape(-1, 2)
+    spectra, vectors, scalars = take(np.float64, head[2] * 30).reshape(-1, 30), take(np.float64, head[3] * 3).reshape(-1, 3), take(np.float64, head[4])
+    from ray_tracer_amd import scenes
+    mesh, _, _ = scenes.cornell(8, 8)
+    named = scene_io.load_materials(str(mpath))
+    omm = scene_io.load_objmatmap(os.path.join(cornell_dir, "objmatmap.json"))
+    g = scene_io.compile_material_graphs([named[omm[n]].record() for n in mesh["names"]])
+    assert len(progs) >= 1 and np.array_equal(progs, g["programs"]) and np.array_equal(code, g["code"])
+    assert np.array_equal(spectra, g["spectra"]) and np.array_equal(vectors, g["vectors"]) and np.array_equal(scalars, g["scalars"])
