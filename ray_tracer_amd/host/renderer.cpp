@@ -120,7 +120,7 @@ void Renderer::RenderImage(int nx, int ny, int ns, int spectral_samples, bool, b
 	while (s < ns) {
 		if (stop_rendering) break; // once per pass, renderer.cpp:70
 		int b = std::min(std::max(1, samples_per_pass), ns - s);
-		if (rt_render_pass(gpu, s, b) != RT_OK || rt_render_sync(gpu) != RT_OK) {
+		if (rt_render_pass(gpu, s, b) != RT_OK) { // no sync here: the pass's last paths ride along with the next pass; the downloads finish them
 			last_error = rt_last_error(gpu);
 			std::fprintf(stderr, "%s\n", last_error.c_str());
 			break;

@@ -91,8 +91,7 @@ class Renderer:
             if self.stop_rendering:  # checked once per pass, renderer.cpp:70
                 break
             b = min(max(1, self.samples_per_pass), ns - s)
-            self.ctx.render_pass(s, b)
-            self.ctx.render_sync()
+            self.ctx.render_pass(s, b)  # no sync: the pass's last paths ride along with the next pass; the downloads finish them
             s += b
             if self.preview_img_flag or s == ns:
                 self.preview_img = self.ctx.download_preview(s)
