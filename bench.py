@@ -287,6 +287,10 @@ def main():
             roof["bytes_per_ray"] = bytes_per_ray
             roof["algorithmic_bytes_per_launch"] = k["items"] / max(k["launches"], 1) * bytes_per_ray
             roof["nodes_per_ray"], roof["tris_per_ray"] = cpu_counts["cornell_nodes_per_ray"], cpu_counts["cornell_tris_per_ray"]
+            roof["frac_note"] = ("the algorithmic bytes price every interior-node visit of a binary tree walk at 64 B; the 8-wide tree is cache resident "
+                                 "on this scene, so the fraction can exceed 1 and says little: the kernel is bound by VALU issue here (fp64 triangle "
+                                 "tests at half rate, ~1400 vector instructions per 64 rays) and by the random-line rate of the memory system on the "
+                                 "soup under aux (frac_of_random_line_rate)")
         line = {
             "metric": "spp/s at 1080p (Cornell box, NEE+MIS wavefront integrator); the incoherent closest-hit Mrays/s half of the metric is under aux",
             "value": args.steps * spp * world / dt, "unit": "spp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -59,7 +59,7 @@ bool rt_context::fail_hip(hipError_t e, const char *what)
 
 void rt_context::free_geometry()
 {
-	void **ptrs[] = {&d_nodes, &d_tri_a, &d_tri_b, &d_leaf_tri, &d_tri_face, &d_face_object};
+	void **ptrs[] = {&d_nodes, &d_tri_a, &d_tri_b, &d_leaf_tri, &d_tri_face, &d_face_object, &d_tri_fo};
 	for (void **p : ptrs) {
 		if (*p) (void)hipFree(*p);
 		*p = nullptr;
@@ -204,7 +204,17 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 			return set_err(ctx, RT_ERR_HIP, keep);
 		}
 	}
+	{ // (face, object) per fan triangle
+		std::vector<uint2> fo(nt);
+		for (uint64_t t = 0; t < nt; t++) fo[t] = make_uint2(hs.tri_face[t], hs.face_object[hs.tri_face[t]]);
+		if (!dev_upload(ctx, ctx->d_tri_fo, fo)) {
+			std::string keep = ctx->error;
+			ctx->free_geometry();
+			return set_err(ctx, RT_ERR_HIP, keep);
+		}
+	}
 	ctx->geom.nodes = (const float4 *)ctx->d_nodes;
+	ctx->geom.tri_fo = (const uint2 *)ctx->d_tri_fo;
 	ctx->geom.tri_a = (const double2 *)ctx->d_tri_a;
 	ctx->geom.tri_b = (const double2 *)ctx->d_tri_b;
 	ctx->geom.leaf_tri = (const uint32_t *)ctx->d_leaf_tri;

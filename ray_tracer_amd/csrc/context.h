@@ -25,7 +25,7 @@ struct rt_context {
 
 	// geometry in HBM
 	void *d_nodes = nullptr, *d_tri_a = nullptr, *d_tri_b = nullptr, *d_leaf_tri = nullptr, *d_tri_face = nullptr,
-	     *d_face_object = nullptr;
+	     *d_face_object = nullptr, *d_tri_fo = nullptr;
 	mi355rt::DeviceGeom geom{};
 	uint64_t device_bytes = 0;
 

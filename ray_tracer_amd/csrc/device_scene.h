@@ -18,6 +18,7 @@ struct DeviceGeom {
 	const uint32_t *leaf_tri;
 	const uint32_t *tri_face;    // fan triangle -> face (polygon)
 	const uint32_t *face_object; // face -> obj object
+	const uint2 *tri_fo;         // fan triangle -> (face, object): what a hit record needs, in one read
 	uint32_t n_tris;
 	uint32_t depth;
 };

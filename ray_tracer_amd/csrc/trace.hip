@@ -121,8 +121,12 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 	// diagnostic build only: per-lane trip counts of the three loops (summed into the t64 buffer at the end)
 	unsigned long long st_node_iter = 0, st_node_lanes = 0, st_leaf_iter = 0, st_leaf_lanes = 0, st_outer = 0, st_outer_lanes = 0, st_in_iter = 0, st_in_lanes = 0;
 #define TRACE_COUNT(iter, lanes) do { if (lane == __ffsll((long long)__ballot(true)) - 1) iter++; lanes++; } while (0)
+	// shader-clock time per section of the main loop, accumulated by lane 0 of every wave (sections end where the next begins)
+	long long st_clk[6] = {0, 0, 0, 0, 0, 0}, st_t0 = clock64();
+#define TRACE_LAP(k) do { const long long now_ = clock64(); st_clk[k] += now_ - st_t0; st_t0 = now_; } while (0)
 #else
 #define TRACE_COUNT(iter, lanes) do { } while (0)
+#define TRACE_LAP(k) do { } while (0)
 #endif
 #if TRACE_COOP_LEAF
 	__shared__ uint32_t coop_li[kBlock / 64][64], coop_owner[kBlock / 64][64];
@@ -151,6 +155,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 	float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tmin_f = 0, tfar_f = 0, rscale = 1.0f;
 	double t_best = 0.0;
 	uint32_t best = RT_MISS, best_tri = RT_MISS, oct = 0;
+	uint2 best_fo = make_uint2(RT_MISS, RT_MISS); // (face, object) of the best hit, requested when the hit is accepted: nothing waits for it until the result is written
 	bool found_any = false;
 	int sp = 0;
 	uint32_t g_base = 0, g_mask = 0;               // current group: low byte = pending children (ordered), next byte = imask
@@ -210,6 +215,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				next += (uint64_t)nidle;
 			}
 		}
+		TRACE_LAP(0); // refill
 		if (__ballot(active) == 0) break;
 		if (active) {
 			TRACE_COUNT(st_outer, st_outer_lanes);
@@ -291,6 +297,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 			}
 #if TRACE_COOP_LEAF
 		}
+		TRACE_LAP(1); // node phase
 		// ---- triangle phase, shared by the whole wave.  Lanes hold very different numbers of parked triangles (0 to 8 and more), so
 		// a per-lane loop runs the fp64 tests with a quarter of the lanes.  Instead every (ray, triangle) pair of the wave gets a lane of
 		// its own: pairs are numbered by a prefix sum over the per-lane counts, written to LDS (leaf position + owner lane), and lane j
@@ -333,6 +340,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					}
 					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 					__builtin_amdgcn_wave_barrier();
+					TRACE_LAP(2); // counting, prefix sum, publishing the pairs
 					// workers: one pair each
 					const bool work = r0 + (uint32_t)lane < total;
 					const uint32_t o = work ? coop_owner[wv][lane] : (uint32_t)lane;
@@ -364,6 +372,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					}
 					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 					__builtin_amdgcn_wave_barrier();
+					TRACE_LAP(3); // ray fetch, triangle loads, exact tests
 					// an owner whose t came down forgets the triangle it held; then the hits at the minimum settle the tie
 					if (n_mine && coop_t[wv][lane] != my_t) { my_t = coop_t[wv][lane]; coop_id[wv][lane] = none_id; }
 					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -380,6 +389,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 							t_best = __longlong_as_double((long long)my_t);
 							best = (uint32_t)fin;
 							best_tri = (uint32_t)(fin >> 32);
+							best_fo = g.tri_fo[best_tri];
 							const double ts = t_best * (double)rscale;
 							float tf = (float)ts;
 							if ((double)tf < ts) tf = next_up(tf);
@@ -391,6 +401,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				}
 			}
 		}
+		TRACE_LAP(4); // merging the hits, reading them back
 		if (active) {
 #else
 			// ---- triangle phase: both parked groups
@@ -419,6 +430,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 							t_best = t;
 							best = li;
 							best_tri = tri;
+							best_fo = g.tri_fo[tri];
 							const double ts = t * (double)rscale;
 							float tf = (float)ts;
 							if ((double)tf < ts) tf = next_up(tf);
@@ -441,11 +453,10 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				} else {
 					rt_hit h;
 					if (best != RT_MISS) {
-						const uint32_t face = g.tri_face[best_tri];
 						h.t = (float)t_best;
-						h.prim = face;
+						h.prim = best_fo.x;
 						h.tri = best_tri;
-						h.object = g.face_object[face];
+						h.object = best_fo.y;
 					} else {
 						h.t = __int_as_float(0x7f800000);
 						h.prim = RT_MISS;
@@ -462,6 +473,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				active = false;
 			}
 		}
+		TRACE_LAP(5); // writing results
 	}
 #ifdef TRACE_STATS
 	if (t64 && n > 1000000) {
@@ -470,6 +482,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 		atomicAdd(&sink[2], st_leaf_iter); atomicAdd(&sink[3], st_leaf_lanes);
 		atomicAdd(&sink[4], st_outer); atomicAdd(&sink[5], st_outer_lanes);
 		atomicAdd(&sink[6], st_in_iter); atomicAdd(&sink[7], st_in_lanes);
+		if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&sink[8 + k], (unsigned long long)st_clk[k]);
 	}
 #endif
 }

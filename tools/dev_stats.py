@@ -22,9 +22,13 @@ d_rays = torch.from_numpy(rays).cuda()
 d_hits = torch.empty((m, 4), dtype=torch.int32, device='cuda')
 sink = torch.zeros(m, dtype=torch.float64, device='cuda')
 ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr(), sink.data_ptr()); ctx.render_sync()
-s = sink[:10].view(torch.int64).cpu().numpy()
+s = sink[:16].view(torch.int64).cpu().numpy()
 print("rays %d" % m)
 print("node iters %d lanes/iter %.1f | leaf iters %d lanes/iter %.1f | outer %d lanes %.1f" % (s[0], s[1] / max(s[0], 1), s[2], s[3] / max(s[2], 1), s[4], s[5] / max(s[4], 1)))
 print("per ray: node lane-steps %.2f leaf lane-steps %.2f; per 64 rays: node iters %.1f leaf iters %.1f outer %.1f" % (s[1] / m, s[3] / m, s[0] * 64 / m, s[2] * 64 / m, s[4] * 64 / m))
 if s[6]:
     print("inside tests: iters %d lanes/iter %.1f per ray %.2f; per 64 rays %.1f" % (s[6], s[7] / s[6], s[7] / m, s[6] * 64 / m))
+clk = s[8:14].astype(float)
+if clk.sum() > 0:
+    names = ["refill", "node phase", "count+publish", "fetch+test", "merge+readback", "write results"]
+    print("wave time by section: " + ", ".join("%s %.1f%%" % (n, 100 * c / clk.sum()) for n, c in zip(names, clk)))
