@@ -59,7 +59,7 @@ bool rt_context::fail_hip(hipError_t e, const char *what)
 
 void rt_context::free_geometry()
 {
-	void **ptrs[] = {&d_nodes, &d_tri_a, &d_tri_b, &d_leaf_tri, &d_tri_face, &d_face_object, &d_tri_fo};
+	void **ptrs[] = {&d_nodes, &d_tri, &d_leaf_tri, &d_tri_face, &d_face_object};
 	for (void **p : ptrs) {
 		if (*p) (void)hipFree(*p);
 		*p = nullptr;
@@ -136,25 +136,27 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	if (const char *s = std::getenv("MI355RT_BUILDER")) builder = std::strcmp(s, "device") == 0 ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
 	if (builder == RT_BUILDER_AUTO) builder = nt > 2000000 ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
 	if (nt < 2) builder = RT_BUILDER_HOST_SAH; // the radix tree needs two leaves
-	// fp64 triangle records: v0 + face normal, v1 + v2 (fan order)
-	std::vector<double> tri_a(6 * std::max<uint64_t>(nt, 1), 0.0), tri_b(6 * std::max<uint64_t>(nt, 1), 0.0);
-	auto fill_record = [&](uint64_t slot, uint32_t t) {
+	// fp64 triangle data: v0 + face normal, v1 + v2.  The host builder writes the 128-byte leaf-ordered records of device_scene.h
+	// itself; the device builder takes the two halves in fan order and gathers the records on the GPU.
+	auto fill_halves = [&](double *a, double *b, uint32_t t) {
 		const double *v0, *v1, *v2;
 		hs.tri_vertices(t, v0, v1, v2);
 		const double *fn = &hs.face_normal[3 * (size_t)hs.tri_face[t]];
-		double *a = &tri_a[6 * slot], *b = &tri_b[6 * slot];
 		a[0] = v0[0]; a[1] = v0[1]; a[2] = v0[2]; a[3] = fn[0]; a[4] = fn[1]; a[5] = fn[2];
 		b[0] = v1[0]; b[1] = v1[1]; b[2] = v1[2]; b[3] = v2[0]; b[4] = v2[1]; b[5] = v2[2];
 	};
 	std::vector<uint32_t> tri_leaf(nt);
 	if (builder == RT_BUILDER_DEVICE_LBVH) {
 		// records go up in fan order; the device builds the tree and reorders them
-		for (uint64_t t = 0; t < nt; t++) fill_record(t, (uint32_t)t);
+		std::vector<double> tri_a(6 * nt), tri_b(6 * nt);
+		for (uint64_t t = 0; t < nt; t++) fill_halves(&tri_a[6 * t], &tri_b[6 * t], (uint32_t)t);
 		void *d_a = nullptr, *d_b = nullptr;
 		DeviceBvh built;
+		bool ok = dev_upload(ctx, ctx->d_tri_face, hs.tri_face) && dev_upload(ctx, ctx->d_face_object, hs.face_object);
 		const uint64_t bytes_before = ctx->device_bytes;
-		bool ok = dev_upload(ctx, d_a, tri_a) && dev_upload(ctx, d_b, tri_b);
-		if (ok && build_bvh_device((const double *)d_a, (const double *)d_b, (uint32_t)nt, ctx->stream, built, err) != hipSuccess) {
+		ok = ok && dev_upload(ctx, d_a, tri_a) && dev_upload(ctx, d_b, tri_b);
+		if (ok && build_bvh_device((const double *)d_a, (const double *)d_b, (const uint32_t *)ctx->d_tri_face, (const uint32_t *)ctx->d_face_object,
+		                           (uint32_t)nt, ctx->stream, built, err) != hipSuccess) {
 			ctx->error = err;
 			ok = false;
 		}
@@ -163,10 +165,10 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 		ctx->device_bytes = bytes_before; // the fan-order copies are gone again
 		if (ok) {
 			ctx->d_nodes = built.nodes;
-			ctx->d_tri_a = built.tri_a;
-			ctx->d_tri_b = built.tri_b;
+			ctx->d_tri = built.tri;
+			ctx->geom.tri_stride = built.tri_stride;
 			ctx->d_leaf_tri = built.leaf_tri;
-			ctx->device_bytes += (uint64_t)built.n_nodes * sizeof(WideNode) + nt * (96 + 4);
+			ctx->device_bytes += (uint64_t)built.n_nodes * sizeof(WideNode) + nt * (16 * (uint64_t)built.tri_stride + 4);
 			ctx->bvh = Bvh2();
 			ctx->wide = BvhWide();
 			ctx->wide.depth = built.depth;
@@ -179,7 +181,6 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 			     !ctx->fail_hip(hipMemcpy(tri_leaf.data(), built.tri_leaf, nt * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy(triangle positions)");
 			(void)hipFree(built.tri_leaf);
 		}
-		ok = ok && dev_upload(ctx, ctx->d_tri_face, hs.tri_face) && dev_upload(ctx, ctx->d_face_object, hs.face_object);
 		if (!ok) {
 			std::string keep = ctx->error;
 			ctx->free_geometry();
@@ -191,12 +192,18 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 		build_bvh(ctx->host, opt, ctx->bvh, ctx->wide);
 		ctx->built_on_device = false;
 		ctx->device_nodes = ctx->wide.nodes.size();
+		const uint32_t stride = triangle_record_stride(nt);
+		ctx->geom.tri_stride = stride;
+		std::vector<double> recs(2 * (size_t)stride * std::max<uint64_t>(nt, 1), 0.0);
 		for (uint64_t li = 0; li < nt; li++) { // leaf-ordered records
 			const uint32_t t = ctx->wide.tri_index[li];
 			tri_leaf[t] = (uint32_t)li;
-			fill_record(li, t);
+			double *rec = &recs[2 * (size_t)stride * li];
+			fill_halves(rec, rec + 6, t);
+			const uint32_t meta[4] = {t, hs.tri_face[t], hs.face_object[hs.tri_face[t]], 0u};
+			std::memcpy(rec + 12, meta, sizeof(meta));
 		}
-		if (!dev_upload(ctx, ctx->d_nodes, ctx->wide.nodes) || !dev_upload(ctx, ctx->d_tri_a, tri_a) || !dev_upload(ctx, ctx->d_tri_b, tri_b) ||
+		if (!dev_upload(ctx, ctx->d_nodes, ctx->wide.nodes) || !dev_upload(ctx, ctx->d_tri, recs) ||
 		    !dev_upload(ctx, ctx->d_leaf_tri, ctx->wide.tri_index) || !dev_upload(ctx, ctx->d_tri_face, hs.tri_face) ||
 		    !dev_upload(ctx, ctx->d_face_object, hs.face_object)) {
 			std::string keep = ctx->error;
@@ -204,19 +211,8 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 			return set_err(ctx, RT_ERR_HIP, keep);
 		}
 	}
-	{ // (face, object) per fan triangle
-		std::vector<uint2> fo(nt);
-		for (uint64_t t = 0; t < nt; t++) fo[t] = make_uint2(hs.tri_face[t], hs.face_object[hs.tri_face[t]]);
-		if (!dev_upload(ctx, ctx->d_tri_fo, fo)) {
-			std::string keep = ctx->error;
-			ctx->free_geometry();
-			return set_err(ctx, RT_ERR_HIP, keep);
-		}
-	}
 	ctx->geom.nodes = (const float4 *)ctx->d_nodes;
-	ctx->geom.tri_fo = (const uint2 *)ctx->d_tri_fo;
-	ctx->geom.tri_a = (const double2 *)ctx->d_tri_a;
-	ctx->geom.tri_b = (const double2 *)ctx->d_tri_b;
+	ctx->geom.tri = (const double2 *)ctx->d_tri;
 	ctx->geom.leaf_tri = (const uint32_t *)ctx->d_leaf_tri;
 	ctx->geom.tri_face = (const uint32_t *)ctx->d_tri_face;
 	ctx->geom.face_object = (const uint32_t *)ctx->d_face_object;

@@ -24,8 +24,8 @@ struct rt_context {
 	uint64_t device_nodes = 0;     // nodes of the tree in HBM
 
 	// geometry in HBM
-	void *d_nodes = nullptr, *d_tri_a = nullptr, *d_tri_b = nullptr, *d_leaf_tri = nullptr, *d_tri_face = nullptr,
-	     *d_face_object = nullptr, *d_tri_fo = nullptr;
+	void *d_nodes = nullptr, *d_tri = nullptr, *d_leaf_tri = nullptr, *d_tri_face = nullptr,
+	     *d_face_object = nullptr;
 	mi355rt::DeviceGeom geom{};
 	uint64_t device_bytes = 0;
 

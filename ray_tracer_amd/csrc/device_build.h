@@ -11,14 +11,19 @@ struct DeviceBvh {
 	void *nodes = nullptr;        // WideNode[n_nodes]
 	uint32_t *leaf_tri = nullptr; // leaf order -> fan triangle
 	uint32_t *tri_leaf = nullptr; // fan triangle -> leaf order
-	void *tri_a = nullptr;        // leaf-ordered records: v0, face normal (6 doubles)
-	void *tri_b = nullptr;        // leaf-ordered records: v1, v2 (6 doubles)
+	void *tri = nullptr;          // leaf-ordered triangle records (device_scene.h)
+	uint32_t tri_stride = 8;      // double2 per record
 	uint32_t n_nodes = 0;
 	uint32_t depth = 0;           // nodes on the longest root-to-leaf path
 	double seconds = 0.0;         // wall time of the build, device work included
 };
 
-// d_tri_a_fan / d_tri_b_fan: the same 6-double records in fan-triangle order, already on the device
-hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan, uint32_t n, hipStream_t stream, DeviceBvh &out, std::string &err);
+// double2 per triangle record: a line of its own (8) once the records outgrow the caches (4 MB of L2 per XCD), packed (7) below that
+inline uint32_t triangle_record_stride(uint64_t n_tris) { return n_tris * 128 > (4u << 20) ? 8u : 7u; }
+
+// d_tri_a_fan / d_tri_b_fan: 6-double records (v0 + face normal, v1 + v2) in fan-triangle order, already on the device;
+// d_tri_face / d_face_object: fan triangle -> face, face -> obj object (for the records' last quarter)
+hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan, const uint32_t *d_tri_face, const uint32_t *d_face_object,
+                            uint32_t n, hipStream_t stream, DeviceBvh &out, std::string &err);
 
 } // namespace mi355rt

@@ -381,16 +381,21 @@ __global__ void __launch_bounds__(kBlock) k_collapse(const BinNode *__restrict__
 }
 
 __global__ void __launch_bounds__(kBlock) k_gather(const double2 *__restrict__ a_in, const double2 *__restrict__ b_in,
-                                                   const uint32_t *__restrict__ leaf_tri, uint32_t n, double2 *__restrict__ a_out,
-                                                   double2 *__restrict__ b_out, uint32_t *__restrict__ tri_leaf)
+                                                   const uint32_t *__restrict__ tri_face, const uint32_t *__restrict__ face_object,
+                                                   const uint32_t *__restrict__ leaf_tri, uint32_t n, uint32_t stride, double2 *__restrict__ rec_out,
+                                                   uint32_t *__restrict__ tri_leaf)
 {
 	const uint32_t li = blockIdx.x * kBlock + threadIdx.x;
 	if (li >= n) return;
 	const uint32_t t = leaf_tri[li];
+	double2 *rec = rec_out + (size_t)stride * li;
 	for (int k = 0; k < 3; k++) {
-		a_out[3 * (size_t)li + k] = a_in[3 * (size_t)t + k];
-		b_out[3 * (size_t)li + k] = b_in[3 * (size_t)t + k];
+		rec[k] = a_in[3 * (size_t)t + k];
+		rec[3 + k] = b_in[3 * (size_t)t + k];
 	}
+	const uint32_t face = tri_face[t];
+	reinterpret_cast<uint4 *>(rec)[6] = make_uint4(t, face, face_object[face], 0u);
+	if (stride > 7) rec[7] = make_double2(0.0, 0.0);
 	tri_leaf[t] = li;
 }
 
@@ -405,7 +410,8 @@ hipError_t dalloc(T *&p, size_t count, std::vector<void *> &owned)
 
 } // namespace
 
-hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan, uint32_t n, hipStream_t stream, DeviceBvh &out, std::string &err)
+hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan, const uint32_t *d_tri_face, const uint32_t *d_face_object,
+                            uint32_t n, hipStream_t stream, DeviceBvh &out, std::string &err)
 {
 	out = DeviceBvh();
 	if (n < 2) { err = "build_bvh_device: needs at least two triangles"; return hipErrorInvalidValue; }
@@ -492,17 +498,17 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	std::vector<void *> keep;
 	WideNode *nodes_out = nullptr;
 	uint32_t *leaf_out = nullptr, *tri_leaf = nullptr;
-	double2 *a_out = nullptr, *b_out = nullptr;
+	double2 *rec_out = nullptr;
 	hipError_t e = dalloc(nodes_out, n_nodes, keep);
 	if (e == hipSuccess) e = dalloc(leaf_out, n, keep);
 	if (e == hipSuccess) e = dalloc(tri_leaf, n, keep);
-	if (e == hipSuccess) e = dalloc(a_out, 3 * (size_t)n, keep);
-	if (e == hipSuccess) e = dalloc(b_out, 3 * (size_t)n, keep);
+	out.tri_stride = triangle_record_stride(n);
+	if (e == hipSuccess) e = dalloc(rec_out, (size_t)out.tri_stride * n, keep);
 	if (e == hipSuccess) e = hipMemcpyAsync(nodes_out, wide, sizeof(WideNode) * n_nodes, hipMemcpyDeviceToDevice, stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(leaf_out, leaf_tri, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_gather, dim3(blocks_n), dim3(kBlock), 0, stream, (const double2 *)d_tri_a_fan, (const double2 *)d_tri_b_fan, leaf_tri, n,
-		                   a_out, b_out, tri_leaf);
+		hipLaunchKernelGGL(k_gather, dim3(blocks_n), dim3(kBlock), 0, stream, (const double2 *)d_tri_a_fan, (const double2 *)d_tri_b_fan, d_tri_face, d_face_object,
+		                   leaf_tri, n, out.tri_stride, rec_out, tri_leaf);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -514,8 +520,7 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	out.nodes = nodes_out;
 	out.leaf_tri = leaf_out;
 	out.tri_leaf = tri_leaf;
-	out.tri_a = a_out;
-	out.tri_b = b_out;
+	out.tri = rec_out;
 	out.n_nodes = n_nodes;
 	out.depth = depth;
 	out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

@@ -8,17 +8,22 @@ namespace mi355rt {
 
 // Geometry the traversal kernels read.
 //   nodes     WideNode (bvh_builder.h), 128 bytes each, read as 5 x uint4 (80 bytes are used)
-//   tri_a     per leaf-ordered triangle, 6 doubles: v0.xyz, face_normal.xyz   (the plane; enough to compute t)
-//   tri_b     per leaf-ordered triangle, 6 doubles: v1.xyz, v2.xyz            (read only when t is in range)
+//   tri       per leaf-ordered triangle one record of tri_stride double2 (8 = one 128-byte line; 7 for scenes small enough to live
+//             in the caches, where density counts and alignment does not):
+//               [0..2] v0.xyz, face_normal.xyz   (the plane; enough to compute t)
+//               [3..5] v1.xyz, v2.xyz
+//               [6]    as uint4: fan triangle, face (polygon), obj object, 0     (what a hit record needs)
+//               [7]    unused
+//             One triangle test touches exactly one line; two 48-byte records in separate arrays straddled lines 37 % of the
+//             time and cost 2.75 lines per test, the largest item after the nodes on scenes that wait for memory.
 //   leaf_tri  leaf order -> fan triangle id
 struct DeviceGeom {
 	const float4 *nodes;
-	const double2 *tri_a;
-	const double2 *tri_b;
+	const double2 *tri;
+	uint32_t tri_stride;         // double2 per triangle record: 7 or 8
 	const uint32_t *leaf_tri;
 	const uint32_t *tri_face;    // fan triangle -> face (polygon)
 	const uint32_t *face_object; // face -> obj object
-	const uint2 *tri_fo;         // fan triangle -> (face, object): what a hit record needs, in one read
 	uint32_t n_tris;
 	uint32_t depth;
 };

@@ -801,8 +801,8 @@ __device__ bool face_hit_exact(const DeviceGeom &g, const DeviceShade &sh, uint3
 	const double ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
 	for (uint32_t t = t0; t < t1; t++) {
 		const uint32_t li = sh.tri_leaf[t];
-		const double2 a0 = g.tri_a[3 * (size_t)li], a1 = g.tri_a[3 * (size_t)li + 1], a2 = g.tri_a[3 * (size_t)li + 2];
-		const double2 b0 = g.tri_b[3 * (size_t)li], b1 = g.tri_b[3 * (size_t)li + 1], b2 = g.tri_b[3 * (size_t)li + 2];
+		const double2 *rec = g.tri + (size_t)g.tri_stride * li;
+		const double2 a0 = rec[0], a1 = rec[1], a2 = rec[2], b0 = rec[3], b1 = rec[4], b2 = rec[5];
 		const double v0x = a0.x, v0y = a0.y, v0z = a1.x, nx = a1.y, ny = a2.x, nz = a2.y;
 		const double v1x = b0.x, v1y = b0.y, v1z = b1.x, v2x = b1.y, v2y = b2.x, v2z = b2.y;
 		const double num = (v0x - ox) * nx + (v0y - oy) * ny + (v0z - oz) * nz;

@@ -354,10 +354,9 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					if (work) {
 						TRACE_COUNT(st_leaf_iter, st_leaf_lanes);
 						const double cur_best = __longlong_as_double((long long)coop_t[wv][o]);
-						// both halves of the record are requested at once: nine in ten plane distances lie in range and need the
-						// second half, and one memory latency per round instead of two is worth the few wasted lines
-						const double2 a0 = g.tri_a[3 * (size_t)li], a1 = g.tri_a[3 * (size_t)li + 1], a2 = g.tri_a[3 * (size_t)li + 2];
-						const double2 b0 = g.tri_b[3 * (size_t)li], b1 = g.tri_b[3 * (size_t)li + 1], b2 = g.tri_b[3 * (size_t)li + 2];
+						// the whole record is requested at once: nine in ten plane distances lie in range and need the second half
+						const double2 *rec = g.tri + (size_t)g.tri_stride * li; // one 128-byte line per triangle
+						const double2 a0 = rec[0], a1 = rec[1], a2 = rec[2], b0 = rec[3], b1 = rec[4], b2 = rec[5];
 						// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz); b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
 						const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
 						if (t >= r.tmin && t <= cur_best) {
@@ -365,7 +364,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 							if (inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) {
 								hit = true;
 								bits = (unsigned long long)__double_as_longlong(t + 0.0); // -0.0 -> +0.0: keeps bit order = numeric order
-								id = ANY ? 0ull : (((unsigned long long)g.leaf_tri[li] << 32) | li);
+								id = ANY ? 0ull : (((unsigned long long)reinterpret_cast<const uint4 *>(rec)[6].x << 32) | li);
 								__hip_atomic_fetch_min(&coop_t[wv][o], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 							}
 						}
@@ -389,7 +388,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 							t_best = __longlong_as_double((long long)my_t);
 							best = (uint32_t)fin;
 							best_tri = (uint32_t)(fin >> 32);
-							best_fo = g.tri_fo[best_tri];
+							{ const uint4 m = reinterpret_cast<const uint4 *>(g.tri + (size_t)g.tri_stride * best)[6]; best_fo = make_uint2(m.y, m.z); }
 							const double ts = t_best * (double)rscale;
 							float tf = (float)ts;
 							if ((double)tf < ts) tf = next_up(tf);
@@ -416,21 +415,23 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					for (uint32_t k = 0; k < count; k++) {
 						TRACE_COUNT(st_leaf_iter, st_leaf_lanes);
 						const uint32_t li = first + k;
-						const double2 a0 = g.tri_a[3 * (size_t)li], a1 = g.tri_a[3 * (size_t)li + 1], a2 = g.tri_a[3 * (size_t)li + 2];
+						const double2 *rec = g.tri + (size_t)g.tri_stride * li;
+						const double2 a0 = rec[0], a1 = rec[1], a2 = rec[2];
 						// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz)
 						const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
 						if (!(t >= r.tmin && t <= t_best)) continue;
 						TRACE_COUNT(st_in_iter, st_in_lanes);
-						const double2 b0 = g.tri_b[3 * (size_t)li], b1 = g.tri_b[3 * (size_t)li + 1], b2 = g.tri_b[3 * (size_t)li + 2];
+						const double2 b0 = rec[3], b1 = rec[4], b2 = rec[5];
 						// b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
 						if (!inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) continue;
 						if (ANY) { found_any = true; break; }
-						const uint32_t tri = g.leaf_tri[li];
+						const uint4 meta = reinterpret_cast<const uint4 *>(rec)[6];
+						const uint32_t tri = meta.x;
 						if (t < t_best || best == RT_MISS || tri < best_tri) { // ties in t: lowest fan triangle
 							t_best = t;
 							best = li;
 							best_tri = tri;
-							best_fo = g.tri_fo[tri];
+							best_fo = make_uint2(meta.y, meta.z);
 							const double ts = t * (double)rscale;
 							float tf = (float)ts;
 							if ((double)tf < ts) tf = next_up(tf);
