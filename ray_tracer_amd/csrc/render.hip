@@ -627,12 +627,15 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBan
 // 16:9) are not queued: they would be traced to a miss and shaded to nothing.  Survivors are appended at the queue tail; rays and
 // state point at the queue's start.  One atomic on the tail per workgroup of 1024 threads x 4 samples: a workgroup per 256 samples
 // made 130 k same-address atomics per 1080p batch, 1.3 ms where the whole kernel takes 0.4.
+// BDPT: a sample whose camera ray misses the scene has no eye vertex and contributes nothing (its light subpath would be walked for
+// nothing): the survivors' sample records are compacted the same way, and the path state names the record's slot.
 constexpr int kGenBlock = 1024, kGenPer = 4;
+template <bool BDPT>
 __global__ void __launch_bounds__(kGenBlock) k_generate_cull(DevCamera cam, const DevBand *__restrict__ bands, uint32_t n_bands,
                                                              int nx, int ny, int ns, int first_sample, uint64_t n_paths,
                                                              uint64_t seed, float tmin, rt_ray *__restrict__ rays,
-                                                             PathState *__restrict__ state, float4 box_lo, float4 box_hi,
-                                                             unsigned long long *__restrict__ tails)
+                                                             PathState *__restrict__ state, BdptSample *__restrict__ samples, float4 box_lo,
+                                                             float4 box_hi, unsigned long long *__restrict__ tails)
 {
 	__shared__ uint32_t s_wave[kGenBlock / 64];
 	__shared__ uint32_t s_base;
@@ -667,6 +670,16 @@ __global__ void __launch_bounds__(kGenBlock) k_generate_cull(DevCamera cam, cons
 		if ((kept[j] >> lane) & 1ull) {
 			const uint32_t slot = at + (uint32_t)__popcll(kept[j] & lt);
 			rays[slot] = r[j];
+			if (BDPT) {
+				BdptSample smp{};
+				smp.rng = st[j].rng;
+				smp.weight = st[j].weight;
+				smp.pixel = st[j].pixel;
+				smp.band_k_l = st[j].band_bounce;
+				samples[slot] = smp;
+				st[j].weight = 1.0f;
+				st[j].pixel = slot;
+			}
 			state[slot] = st[j];
 		}
 		at += (uint32_t)__popcll(kept[j]);
@@ -1330,8 +1343,9 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 			prof.begin(Profiler::GENERATE, n_paths, stream);
 			if (cull_camera) {
 				const unsigned cull_blocks = (unsigned)((n_paths + kGenBlock * kGenPer - 1) / (kGenBlock * kGenPer));
-				hipLaunchKernelGGL(k_generate_cull, dim3(cull_blocks), dim3(kGenBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns,
-				                   first_sample, n_paths, rs.seed, tmin, im.rays[cur], im.state[cur], im.scene_lo, im.scene_hi, &im.counters[0].tails);
+				hipLaunchKernelGGL(k_generate_cull<false>, dim3(cull_blocks), dim3(kGenBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns,
+				                   first_sample, n_paths, rs.seed, tmin, im.rays[cur], im.state[cur], (BdptSample *)nullptr, im.scene_lo, im.scene_hi,
+				                   &im.counters[0].tails);
 				// the queue length is what the kernel left in the counter; the host keeps its upper bound
 				HIP_TRY(hipMemcpyAsync(&im.h_counters[0], &im.counters[0], sizeof(Counters), hipMemcpyDeviceToHost, stream));
 			} else {
@@ -1453,19 +1467,33 @@ static hipError_t ensure_bdpt(Impl &im, uint64_t cap, hipStream_t stream, std::s
 // one batch of NaiveBDPT samples (see render_bdpt.inc for the stages)
 static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err)
 {
-	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_paths = npix * (uint64_t)n_samples;
-	const uint32_t n = (uint32_t)n_paths;
+	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_generated = npix * (uint64_t)n_samples;
 	const DeviceShade sh = make_shade(im);
 	Profiler nop, &prof = rs.profiler ? *rs.profiler : nop;
 	BdptSample *samples = static_cast<BdptSample *>(im.bdpt_samples);
 	BdptVertex *verts = static_cast<BdptVertex *>(im.bdpt_verts);
+	uint64_t n_paths = n_generated; // samples that take part: all, or those whose camera ray can touch the scene
+	prof.begin(Profiler::GENERATE, n_generated, stream);
+	if (im.cull_connections) {
+		HIP_TRY(hipMemsetAsync(im.counters, 0, sizeof(Counters), stream));
+		const unsigned cull_blocks = (unsigned)((n_generated + kGenBlock * kGenPer - 1) / (kGenBlock * kGenPer));
+		hipLaunchKernelGGL(k_generate_cull<true>, dim3(cull_blocks), dim3(kGenBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns,
+		                   first_sample, n_generated, rs.seed, 0.001f, im.rays[0], im.state[0], samples, im.scene_lo, im.scene_hi, &im.counters[0].tails);
+		prof.end(stream);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(&im.h_counters[0], &im.counters[0], sizeof(Counters), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream)); // one wait per batch of up to 2^25 samples: everything below is sized by the count
+		n_paths = (uint32_t)im.h_counters[0].tails;
+	} else {
+		hipLaunchKernelGGL(k_generate<true>, dim3((unsigned)((n_generated + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands, im.n_bands,
+		                   rs.nx, rs.ny, rs.ns, first_sample, n_generated, rs.seed, 0.001f, im.rays[0], im.state[0], samples);
+		prof.end(stream);
+		HIP_TRY(hipGetLastError());
+	}
+	rs.camera_samples += n_generated;
+	if (n_paths == 0) return hipSuccess;
+	const uint32_t n = (uint32_t)n_paths;
 	const unsigned blocks_n = (unsigned)((n_paths + kBlock - 1) / kBlock);
-	prof.begin(Profiler::GENERATE, n_paths, stream);
-	hipLaunchKernelGGL(k_generate<true>, dim3(blocks_n), dim3(kBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns, first_sample,
-	                   n_paths, rs.seed, 0.001f, im.rays[0], im.state[0], samples);
-	prof.end(stream);
-	HIP_TRY(hipGetLastError());
-	rs.camera_samples += n_paths;
 	// a subpath: trace, walk, repeat.  A walker that survives bounce b has stored b + 1 vertices, so nothing is left after
 	// kBdptMax + 1 bounces.  Counts stay on the device (slot base + b of the counters, read by the kernels of bounce b); the
 	// host only uses the copies that have already arrived to shrink the grids, and never waits for one.

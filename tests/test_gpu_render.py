@@ -259,10 +259,13 @@ def test_mis_bdpt_is_black(ctx, cornell_dir):
     assert not ctx.download_film().any()
 
 
-def test_naive_bdpt_statistics(ctx, cornell_dir):
+def test_naive_bdpt_statistics(ctx, cornell_dir, monkeypatch):
     """ray counts per camera sample: the reference traces 7.10 closest + 1.30 occlusion rays on this scene (recorded from a reference
-    run), two of the closest-hit traces repeat known results and are not issued here"""
+    run), two of the closest-hit traces repeat known results and are not issued here.  Counted with the diagnostic switch that
+    keeps the samples and rays the device otherwise drops because they cannot contribute."""
+    monkeypatch.setenv("MI355RT_TRACE_ALL_CONNECTIONS", "1")
     g, o, st, gs = render_both(ctx, cornell_dir, 64, 64, 8, 30, capi.ALG_NAIVE_BDPT, seed=4)
+    monkeypatch.delenv("MI355RT_TRACE_ALL_CONNECTIONS")
     n = st["samples"]
     assert abs(st["closest_rays"] / n - 7.10) < 0.1 and abs(st["shadow_rays"] / n - 1.30) < 0.05
     assert abs(gs["any_rays"] / n - st["shadow_rays"] / n) < 1e-9  # same paths: same pairs
