@@ -625,11 +625,17 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBan
 
 // The same, but camera rays that cannot touch the scene's bounding box (a frame wider than the scene: 40 % of the Cornell box at
 // 16:9) are not queued: they would be traced to a miss and shaded to nothing.  Survivors are appended at the queue tail; rays and
-// state point at the queue's start.  One atomic on the tail per workgroup of 1024 threads x 4 samples: a workgroup per 256 samples
+// state point at the queue's start.  One atomic on the tail per workgroup of 512 threads x 4 samples (swept): a workgroup per 256 samples
 // made 130 k same-address atomics per 1080p batch, 1.3 ms where the whole kernel takes 0.4.
 // BDPT: a sample whose camera ray misses the scene has no eye vertex and contributes nothing (its light subpath would be walked for
 // nothing): the survivors' sample records are compacted the same way, and the path state names the record's slot.
-constexpr int kGenBlock = 1024, kGenPer = 4;
+#ifndef GEN_BLOCK
+#define GEN_BLOCK 512
+#endif
+#ifndef GEN_PER
+#define GEN_PER 4
+#endif
+constexpr int kGenBlock = GEN_BLOCK, kGenPer = GEN_PER;
 template <bool BDPT>
 __global__ void __launch_bounds__(kGenBlock) k_generate_cull(DevCamera cam, const DevBand *__restrict__ bands, uint32_t n_bands,
                                                              int nx, int ny, int ns, int first_sample, uint64_t n_paths,
