@@ -387,15 +387,17 @@ __device__ __forceinline__ bool mat_sample(const DevMaterial &m, f3 normal, cons
                                            f3 &vi, float &ratio, float &pdfval, bool light_type = false)
 {
 	switch (m.type) {
-	case RT_MAT_LAMBERTIAN: { // :262-276; CosinePdf builds its own frame from rec.normal (pdf.cpp:36-46,70-84)
-		Onb pb = onb_from_w(normal);
+	case RT_MAT_LAMBERTIAN: { // :262-276.  CosinePdf builds a frame of its own from rec.normal (pdf.cpp:36-46,70-84), maps the sample to
+		// the world and the caller maps it back with its frame: every caller here builds `uvw` from that same normal with the same
+		// function, so the two frames are one, the round trip is the identity (to fp64 rounding in the reference) and
+		// dot(generated, w) is the sample's z.  The sample is used in the local frame directly.
+		(void)normal;
 		float r1 = rng_f32(rng), r2 = rng_f32(rng);
-		float phi = 2.0f * kPi * r1, st = sqrtf(r2), sphi, cphi;
-		sincosf(phi, &sphi, &cphi);
-		f3 gen = l2w(pb, F3(st * cphi, st * sphi, 1.0f - r2)); // z = 1 - r2 as in the reference
-		float cos_theta = dot(gen, pb.w);
+		// phi = 2 pi r1: the hardware sine and cosine take their argument in revolutions
+		const float st = sqrtf(r2), sphi = __builtin_amdgcn_sinf(r1), cphi = __builtin_amdgcn_cosf(r1);
+		vi = F3(st * cphi, st * sphi, 1.0f - r2); // z = 1 - r2 as in the reference
+		const float cos_theta = vi.z;
 		pdfval = cos_theta >= 0.0f ? cos_theta / kPi : 0.0f;
-		vi = w2l(uvw, gen);
 		float bsdf = mat_bsdf(m, vi, vo, a);
 		ratio = bsdf / pdfval;
 		return true;
@@ -833,7 +835,8 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 							c1.c0 = st.beta * ratio * fabsf(gvi.z) * st.weight;
 							c1.c1 = pdfv / fabsf(gvi.z);
 							c1.band_kind = band | (1u << 16);
-							want_c1 = !sh.cull_connections || ray_may_reach_box(sh, sel, p, sdir); // counts only if its closest hit is on the chosen light
+							// counts only if its closest hit is on the chosen light, and not at all with a zero factor
+							want_c1 = !sh.cull_connections || (c1.c0 != 0.0f && ray_may_reach_box(sh, sel, p, sdir));
 						}
 					}
 				}
@@ -844,7 +847,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 				if (ALG == RT_ALG_NAIVE) {
 					if (respawn) {
 						st.beta *= ratio * fabsf(gvi.z);
-						if (!(rng_f32(st.rng) < 0.5f)) { // :211-215
+						if (!(rng_f32(st.rng) < 0.5f) && (st.beta != 0.0f || !sh.cull_connections)) { // :211-215; a zero throughput ends the path
 							st.beta /= 0.5f;
 							const f3 nd = l2w(uvw, gvi); // not re-normalised, :217
 							nr.ox = p.x; nr.oy = p.y; nr.oz = p.z; nr.tmin = tmin;
@@ -857,7 +860,9 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 					const float prr = bounce > 6 ? 0.9f : 0.5f; // :304-310 / 454-460
 					if (!(rng_f32(st.rng) < prr)) {
 						st.beta /= (1.0f - prr);
-						if (respawn) {
+						// a path whose throughput has become exactly zero (a surface that reflects nothing in this band) can add
+						// nothing any more: it is not continued
+						if (respawn && (st.beta != 0.0f || !sh.cull_connections)) {
 							const f3 nd = unit(l2w(uvw, gvi));
 							nr.ox = p.x; nr.oy = p.y; nr.oz = p.z; nr.tmin = tmin;
 							nr.dx = nd.x; nr.dy = nd.y; nr.dz = nd.z; nr.tmax = __int_as_float(0x7f800000);
