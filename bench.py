@@ -303,6 +303,7 @@ def main():
             "msamples_per_s": args.steps * spp * world * nx * ny / dt / 1e6,
             "rays_per_sample": (stats["closest_rays"] + stats["any_rays"]) / max(stats["camera_samples"], 1),
             "kernels_ms": {name: v["ms"] for name, v in prof.items()},
+            "kernel_items": {name: v["items"] for name, v in prof.items()},
             "film_mean_per_pixel": film_mean, "film_finite": ok,
             "roofline": roof,
             "cpu_baseline": cpu["cpu"] if cpu is not None else None,
