@@ -107,6 +107,12 @@ constexpr int kMaxBounces = 62; // counter slots per batch; a longer path wraps 
 #define SHADE_MIN_BLOCKS 1
 #endif
 constexpr int kShadeBlock = SHADE_BLOCK;
+#ifndef STREAM_GRID_WAVES
+#define STREAM_GRID_WAVES 64
+#endif
+// workgroups for a kernel that walks a queue of at most `bound` items in strides: enough waves to fill the chip several times over
+// (256 CUs x STREAM_GRID_WAVES waves), never more than the bound needs
+inline unsigned stream_grid(uint64_t bound, int block, int waves = STREAM_GRID_WAVES) { return (unsigned)std::min<uint64_t>((bound + block - 1) / block, 256ull * waves * 64 / block); }
 
 struct Impl {
 	// shading data
@@ -747,7 +753,8 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 {
 	const uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
 	// grids are sized from an upper bound of the queue length (the count of two bounces ago): most workgroups of a
-	// late bounce lie wholly beyond the queue and leave before the slot reservation below (uniform per workgroup)
+	// late bounce lie wholly beyond the queue and leave before the slot reservation below (uniform per workgroup).
+	// (Walking the queue in strides with a capped grid, as k_connect does, made this kernel 30 % slower.)
 	if (blockIdx.x * kShadeBlock >= *n_dev) return;
 	const bool live = idx < *n_dev;
 	bool survive = false, want_c0 = false, want_c1 = false;
@@ -918,19 +925,22 @@ __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh
                                                     const ConnRec *__restrict__ conn, const rt_hit *__restrict__ conn_hits,
                                                     const uint8_t *__restrict__ conn_any, float *__restrict__ film)
 {
-	const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
-	if (idx >= *n_dev) return;
+	// The host only knows an upper bound of the queue length (the count of two bounces ago, or nothing better than the batch size
+	// right after the camera rays were culled on the device): a grid sized by it launched up to ten times more workgroups than
+	// there was work for, 30-60 us per kernel.  The grid is capped (stream_grid) and the queue is walked in strides.
+	const uint32_t n_items = *n_dev;
+	for (uint32_t idx = blockIdx.x * kBlock + threadIdx.x; idx < n_items; idx += gridDim.x * kBlock) {
 	const ConnRec c = conn[idx];
 	const DevBand bd = sh.bands[c.band_kind & 0xFFFFu];
 	const uint32_t kind = c.band_kind >> 16;
 	if (ALG == RT_ALG_NEE) {
-		if (conn_any[idx]) return; // occluded, renderer.cpp:263
+		if (conn_any[idx]) continue; // occluded, renderer.cpp:263
 		const rt_ray r = conn_rays[idx];
 		if (face_hit_exact(g, sh, c.sel_face, r, 0.0001, (double)c.c1 + 0.0001)) film_add(film, c.pixel, bd, c.c0);
-		return;
+		continue;
 	}
 	const rt_hit h = conn_hits[idx];
-	if (h.prim == RT_MISS || h.prim != c.sel_face) return; // renderer.cpp:373-376 / 419-421
+	if (h.prim == RT_MISS || h.prim != c.sel_face) continue; // renderer.cpp:373-376 / 419-421
 	const rt_ray r = conn_rays[idx];
 	const f3 o = F3(r.ox, r.oy, r.oz), d = F3(r.dx, r.dy, r.dz);
 	const f3 pl = o + h.t * d;
@@ -948,6 +958,7 @@ __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh
 	if (kind == 0) add = power_heuristic2(lpa, c.c1 * G) * (c.c0 * G) * light;      // renderer.cpp:390-399
 	else add = power_heuristic2(G * c.c1, lpa) * c.c0 * light;                      // renderer.cpp:422-429
 	film_add(film, c.pixel, bd, add);
+	}
 }
 
 #include "render_bdpt.inc"
@@ -1416,7 +1427,7 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 					}
 					rec_conn[b] = prof.last();
 					prof.begin(Profiler::CONNECT, conn_bound, stream);
-					hipLaunchKernelGGL((k_connect<ALG>), dim3((unsigned)((conn_bound + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, geom, sh,
+					hipLaunchKernelGGL((k_connect<ALG>), dim3(stream_grid(conn_bound, kBlock)), dim3(kBlock), 0, stream, geom, sh,
 					                   n_conn, im.conn_rays, im.conn, im.conn_hits, im.conn_any, rs.d_film);
 					prof.end(stream);
 					HIP_TRY(hipGetLastError());
