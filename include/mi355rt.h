@@ -206,7 +206,10 @@ int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d
 /* replaces: the set-up of Renderer::RenderImage (renderer.cpp:56-58): sizes and clears the film
  * (nx*ny*30 floats, element (i*ny+j)*30+bin, the reference's column-major pixel order).
  * d_film: optional caller-owned device buffer of nx*ny*30 floats (e.g. memory an RCCL all-reduce
- * will run on); NULL = the context allocates it. */
+ * will run on); NULL = the context allocates it.
+ * Rays and samples that cannot add to the film are dropped where that is certain (camera rays that miss the scene's bounding
+ * box, BSDF-sampled light rays that miss the chosen light's box, paths with zero throughput); the film is the same without that.
+ * The environment variable MI355RT_TRACE_ALL_CONNECTIONS=1, read here, switches it off (tests, ray statistics). */
 int rt_render_begin(rt_context *ctx, int nx, int ny, int ns, int spectral_samples, int algorithm, uint64_t seed, void *d_film);
 /* replaces: passes s = first_sample .. first_sample+n_samples-1 of the loop at renderer.cpp:69-123
  * (camera ray, integrator, film weight, Spectrum::add of rad/ns).  Work is queued on the context's stream.
