@@ -320,15 +320,18 @@ __device__ float eval_graph(const DeviceShade &sh, uint32_t begin, uint32_t len,
 }
 
 // slot a of the material at a hit with texture coordinate uv, read at one bin
+// GRAPHS = false: instantiations for scenes without per-hit programs, which then carry none of the evaluator's registers
+template <bool GRAPHS = true>
 __device__ __forceinline__ float slot_a(const DeviceShade &sh, const DevMaterial &m, f3 uv, int bin)
 {
-	return m.prog_len ? eval_graph(sh, m.prog_begin, m.prog_len, uv, bin) : m.a[bin];
+	return (GRAPHS && m.prog_len) ? eval_graph(sh, m.prog_begin, m.prog_len, uv, bin) : m.a[bin];
 }
 
+template <bool GRAPHS = true>
 __device__ __forceinline__ float mat_emitted(const DeviceShade &sh, const DevMaterial &m, f3 uv, const DevBand &bd) // materialnode.cpp:215-218,739-749
 {
 	if (m.type != RT_MAT_DIFFUSE_LIGHT) return 0.0f;
-	if (!m.prog_len) return spectrum_integrate(m.a, bd);
+	if (!GRAPHS || !m.prog_len) return spectrum_integrate(m.a, bd);
 	float sum = 0.0f; // Spectrum::integrate (spectrum.cpp:126-146) over the spectrum the graph yields at this hit
 	if (bd.flags & 1) sum += eval_graph(sh, m.prog_begin, m.prog_len, uv, bd.min_i - 1) * bd.mod_min;
 	if (bd.flags & 2) sum += eval_graph(sh, m.prog_begin, m.prog_len, uv, bd.max_i + 1) * bd.mod_max;
@@ -744,7 +747,7 @@ __device__ __forceinline__ bool ray_may_reach_box(const DeviceShade &sh, uint32_
 	return ray_may_reach(sh.light_box[2 * sel], sh.light_box[2 * sel + 1], o, d);
 }
 
-template <int ALG>
+template <int ALG, bool GRAPHS>
 __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceShade sh, const uint32_t *__restrict__ n_dev, const rt_ray *__restrict__ rays,
                                                   const PathState *__restrict__ state, const rt_hit *__restrict__ hits,
                                                   rt_ray *__restrict__ next_rays, PathState *__restrict__ next_state,
@@ -777,15 +780,15 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 			const TriShade tri = load_tri(sh.tri_shade, h.tri);
 			const f3 nrm = shading_normal(tri, p);
 			const DevMaterial &m = sh.materials[h.object];
-			const f3 uv = m.prog_len ? hit_uv(sh, h.tri, tri, p) : F3(0, 0, 0); // rec.vt, only read by per-hit material graphs
-			const float a_bin = slot_a(sh, m, uv, bd.get_bin);
+			const f3 uv = (GRAPHS && m.prog_len) ? hit_uv(sh, h.tri, tri, p) : F3(0, 0, 0); // rec.vt, only read by per-hit material graphs
+			const float a_bin = slot_a<GRAPHS>(sh, m, uv, bd.get_bin);
 			const float tmin = r.tmin;
 			bool alive = true;
 			if (ALG == RT_ALG_NAIVE) {
-				film_add(film, st.pixel, bd, st.beta * mat_emitted(sh, m, uv, bd) * st.weight); // renderer.cpp:197
+				film_add(film, st.pixel, bd, st.beta * mat_emitted<GRAPHS>(sh, m, uv, bd) * st.weight); // renderer.cpp:197
 			} else if (m.light_flag) { // renderer.cpp:242-251 / 346-355
 				if (bounce != 0) alive = false;
-				else film_add(film, st.pixel, bd, mat_emitted(sh, m, uv, bd) * st.weight);
+				else film_add(film, st.pixel, bd, mat_emitted<GRAPHS>(sh, m, uv, bd) * st.weight);
 			}
 			if (alive) {
 				const Onb uvw = onb_from_w(nrm);
@@ -819,7 +822,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 						cr0.tmax = dist - 0.0001f;
 						const float G = fabsf(dot(sd, ltri.fn) * dot(sd, nrm) / dot(to_l, to_l));
 						const DevMaterial &lm = sh.materials[sh.face_object[lf]]; // Emitted(shadow_ray, light_rec, light_rec.vt), :278-282
-						const float light = mat_emitted(sh, lm, lm.prog_len ? hit_uv(sh, lt, ltri, pl) : F3(0, 0, 0), bd);
+						const float light = mat_emitted<GRAPHS>(sh, lm, (GRAPHS && lm.prog_len) ? hit_uv(sh, lt, ltri, pl) : F3(0, 0, 0), bd);
 						c0.c0 = bsdf * st.beta * light * G / lpa * st.weight;
 						c0.c1 = dist;
 						c0.band_kind = band | (2u << 16);
@@ -920,7 +923,7 @@ __device__ bool face_hit_exact(const DeviceGeom &g, const DeviceShade &sh, uint3
 // ---------------------------------------------------------------------------------------------
 // connect: turns visibility results into film contributions
 // ---------------------------------------------------------------------------------------------
-template <int ALG>
+template <int ALG, bool GRAPHS>
 __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh, const uint32_t *__restrict__ n_dev, const rt_ray *__restrict__ conn_rays,
                                                     const ConnRec *__restrict__ conn, const rt_hit *__restrict__ conn_hits,
                                                     const uint8_t *__restrict__ conn_any, float *__restrict__ film)
@@ -952,7 +955,7 @@ __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh
 	const f3 nrm = F3(c.nx, c.ny, c.nz);
 	const float G = fabsf(dot(dir, ln) * dot(dir, nrm) / dot(v, v));
 	const DevMaterial &lm = sh.materials[h.object];
-	const float light = mat_emitted(sh, lm, lm.prog_len ? hit_uv(sh, h.tri, tri, pl) : F3(0, 0, 0), bd);
+	const float light = mat_emitted<GRAPHS>(sh, lm, (GRAPHS && lm.prog_len) ? hit_uv(sh, h.tri, tri, pl) : F3(0, 0, 0), bd);
 	const float lpa = 1.0f / sh.face_area[c.sel_face] / (float)sh.n_lights;
 	float add;
 	if (kind == 0) add = power_heuristic2(lpa, c.c1 * G) * (c.c0 * G) * light;      // renderer.cpp:390-399
@@ -1400,9 +1403,15 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 			prof.end(stream);
 			rec_path[b] = prof.last();
 			prof.begin(Profiler::SHADE, bound, stream);
-			hipLaunchKernelGGL((k_shade<ALG>), dim3((unsigned)((bound + kShadeBlock - 1) / kShadeBlock)), dim3(kShadeBlock), 0, stream, sh, n_path,
-			                   im.rays[cur], im.state[cur], im.hits, im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, im.conn,
-			                   &im.counters[b + 1], rs.d_film);
+			{
+				const dim3 grid((unsigned)((bound + kShadeBlock - 1) / kShadeBlock));
+				if (im.g_code)
+					hipLaunchKernelGGL((k_shade<ALG, true>), grid, dim3(kShadeBlock), 0, stream, sh, n_path, im.rays[cur], im.state[cur], im.hits,
+					                   im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, im.conn, &im.counters[b + 1], rs.d_film);
+				else
+					hipLaunchKernelGGL((k_shade<ALG, false>), grid, dim3(kShadeBlock), 0, stream, sh, n_path, im.rays[cur], im.state[cur], im.hits,
+					                   im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, im.conn, &im.counters[b + 1], rs.d_film);
+			}
 			prof.end(stream);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipMemcpyAsync(&im.h_counters[b + 1], &im.counters[b + 1], sizeof(Counters), hipMemcpyDeviceToHost, stream));
@@ -1427,8 +1436,12 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 					}
 					rec_conn[b] = prof.last();
 					prof.begin(Profiler::CONNECT, conn_bound, stream);
-					hipLaunchKernelGGL((k_connect<ALG>), dim3(stream_grid(conn_bound, kBlock)), dim3(kBlock), 0, stream, geom, sh,
-					                   n_conn, im.conn_rays, im.conn, im.conn_hits, im.conn_any, rs.d_film);
+					if (im.g_code)
+						hipLaunchKernelGGL((k_connect<ALG, true>), dim3(stream_grid(conn_bound, kBlock)), dim3(kBlock), 0, stream, geom, sh,
+						                   n_conn, im.conn_rays, im.conn, im.conn_hits, im.conn_any, rs.d_film);
+					else
+						hipLaunchKernelGGL((k_connect<ALG, false>), dim3(stream_grid(conn_bound, kBlock)), dim3(kBlock), 0, stream, geom, sh,
+						                   n_conn, im.conn_rays, im.conn, im.conn_hits, im.conn_any, rs.d_film);
 					prof.end(stream);
 					HIP_TRY(hipGetLastError());
 					if (rec_conn[b] >= 0) rec_conn[b] = prof.last() - 1;
