@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-step", type=int, default=16)
-    ap.add_argument("--cpu-spp", type=int, default=64)
+    ap.add_argument("--cpu-spp", type=int, default=256)
     ap.add_argument("--soup-tris", type=int, default=1000000)
     ap.add_argument("--soup-sigma", type=float, default=0.004)
     ap.add_argument("--soup-rays", type=int, default=1 << 24)
