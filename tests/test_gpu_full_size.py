@@ -70,6 +70,18 @@ def test_full_hd_render_properties(cornell_dir):
     assert np.allclose(whole, parts, rtol=1e-4, atol=1e-8)
     st = ctx.stats()
     assert st["camera_samples"] == nx * ny * ns
+    # the same samples with nothing dropped (camera rays past the scene, hopeless connections, dead paths): the same film
+    os.environ["MI355RT_TRACE_ALL_CONNECTIONS"] = "1"
+    try:
+        ctx.render_begin(nx, ny, ns, 30, capi.ALG_MIS, 99)
+        for s in range(0, ns, 4):
+            ctx.render_pass(s, 4)
+        everything = ctx.download_film()
+        st_all = ctx.stats()
+    finally:
+        del os.environ["MI355RT_TRACE_ALL_CONNECTIONS"]
+    assert np.allclose(whole, everything, rtol=1e-4, atol=1e-8)
+    assert st_all["camera_samples"] == st["camera_samples"] and st_all["closest_rays"] > 2.0 * st["closest_rays"]
     mean = whole.sum() / (nx * ny)
     m2, r2, c2, oc = oracle.cornell_setup(cornell_dir, 192, 108)
     sc = oracle.Scene(m2)
