@@ -576,10 +576,11 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBan
                                               int first_sample, uint64_t seed, float tmin, uint64_t idx, BdptSample *__restrict__ samples,
                                               rt_ray &r, PathState &st)
 {
-	const uint64_t npix = (uint64_t)nx * ny;
-	const uint32_t pixel = (uint32_t)(idx % npix);
-	const int sample = first_sample + (int)(idx / npix);
-	const int i = pixel / ny, j = pixel % ny;
+	// a batch holds fewer than 2^31 samples (render_pass): 32-bit divisions, a fraction of the cost of 64-bit ones
+	const uint32_t npix = (uint32_t)nx * (uint32_t)ny, idx32 = (uint32_t)idx;
+	const uint32_t sample_off = idx32 / npix, pixel = idx32 - sample_off * npix;
+	const int sample = first_sample + (int)sample_off;
+	const int i = (int)(pixel / (uint32_t)ny), j = (int)(pixel - (uint32_t)i * (uint32_t)ny);
 	uint64_t rng = rng_seed(seed, pixel, (uint64_t)sample);
 	const float u = ((float)i + rng_f32(rng)) / (float)nx;
 	const float v = ((float)j + rng_f32(rng)) / (float)ny;
