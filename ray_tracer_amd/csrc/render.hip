@@ -748,6 +748,12 @@ __device__ __forceinline__ bool ray_may_reach_box(const DeviceShade &sh, uint32_
 	return ray_may_reach(sh.light_box[2 * sel], sh.light_box[2 * sel + 1], o, d);
 }
 
+#ifdef SHADE_CLK
+__device__ unsigned long long g_shade_clk[8];
+#define SHADE_LAP(k) do { const long long n_ = clock64(); clk[k] += n_ - t0_; t0_ = n_; } while (0)
+#else
+#define SHADE_LAP(k) do { } while (0)
+#endif
 template <int ALG, bool GRAPHS>
 __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceShade sh, const uint32_t *__restrict__ n_dev, const rt_ray *__restrict__ rays,
                                                   const PathState *__restrict__ state, const rt_hit *__restrict__ hits,
@@ -760,22 +766,25 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 	// late bounce lie wholly beyond the queue and leave before the slot reservation below (uniform per workgroup).
 	// (Walking the queue in strides with a capped grid, as k_connect does, made this kernel 30 % slower.)
 	if (blockIdx.x * kShadeBlock >= *n_dev) return;
+#ifdef SHADE_CLK
+	long long clk[6] = {0, 0, 0, 0, 0, 0}, t0_ = clock64();
+#endif
 	const bool live = idx < *n_dev;
 	bool survive = false, want_c0 = false, want_c1 = false;
 	rt_ray nr{}, cr0{}, cr1{};
 	ConnRec c0{}, c1{};
 	PathState st{};
 	if (live) {
+		// state, hit and ray are requested together (nearly every queued ray hits something: the ray is rarely read for nothing),
+		// then everything that hangs on them: the kernel spends half its time waiting for these reads
 		st = state[idx];
 		const rt_hit h = hits[idx];
-		if (ALG == RT_ALG_NAIVE && h.prim == RT_MISS && sh.env != nullptr) { // renderer.cpp:175-193
-			const DevBand bd = sh.bands[st.band_bounce & 0xFFFFu];
-			film_add(film, st.pixel, bd, st.beta * environment_radiance(sh, rays[idx], bd.get_bin) * st.weight);
-		}
+		const rt_ray r = rays[idx];
+		const uint32_t band = st.band_bounce & 0xFFFFu, bounce = st.band_bounce >> 16;
+		const DevBand bd = sh.bands[band];
+		if (ALG == RT_ALG_NAIVE && h.prim == RT_MISS && sh.env != nullptr) // renderer.cpp:175-193
+			film_add(film, st.pixel, bd, st.beta * environment_radiance(sh, r, bd.get_bin) * st.weight);
 		if (h.prim != RT_MISS) {
-			const rt_ray r = rays[idx];
-			const uint32_t band = st.band_bounce & 0xFFFFu, bounce = st.band_bounce >> 16;
-			const DevBand bd = sh.bands[band];
 			const f3 o = F3(r.ox, r.oy, r.oz), d = F3(r.dx, r.dy, r.dz);
 			const f3 p = o + h.t * d;
 			const TriShade tri = load_tri(sh.tri_shade, h.tri);
@@ -792,6 +801,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 				else film_add(film, st.pixel, bd, mat_emitted<GRAPHS>(sh, m, uv, bd) * st.weight);
 			}
 			if (alive) {
+				SHADE_LAP(0);
 				const Onb uvw = onb_from_w(nrm);
 				const f3 vo = w2l(uvw, neg(d));
 				if (ALG != RT_ALG_NAIVE) {
@@ -835,6 +845,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 						c0.c1 = spdf / fabsf(dot(sd, nrm));
 						c0.band_kind = band | (0u << 16);
 						want_c0 = c0.c0 != 0.0f;
+						SHADE_LAP(1);
 						// BSDF-sampled direct light, renderer.cpp:404-433
 						f3 gvi;
 						float ratio, pdfv;
@@ -851,6 +862,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 						}
 					}
 				}
+				SHADE_LAP(2);
 				// continuation sample (renderer.cpp:199-208 / 290-300 / 440-450)
 				f3 gvi;
 				float ratio, pdfv;
@@ -885,12 +897,18 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 			}
 		}
 	}
+	SHADE_LAP(3);
 	const Slots sl = reserve_slots(&counters->tails, survive, want_c0, want_c1);
+	SHADE_LAP(4);
 	if (survive) { next_rays[sl.next] = nr; next_state[sl.next] = st; }
 	if (ALG != RT_ALG_NAIVE) {
 		if (want_c0) { conn_rays[sl.c0] = cr0; conn[sl.c0] = c0; }
 		if (want_c1) { conn_rays[sl.c1] = cr1; conn[sl.c1] = c1; }
 	}
+#ifdef SHADE_CLK
+	SHADE_LAP(5);
+	if ((threadIdx.x & 63) == 0) for (int k = 0; k < 6; k++) atomicAdd(&g_shade_clk[k], (unsigned long long)clk[k]);
+#endif
 }
 
 // exact polygon test of one face, as light_objects[sel]->Hit(shadow_ray, ...) at renderer.cpp:278
@@ -1726,6 +1744,15 @@ hipError_t render_set_environment(RenderState &rs, const uint8_t *texels, int wi
 
 void render_free(RenderState &rs)
 {
+#ifdef SHADE_CLK
+	{
+		unsigned long long h[8] = {};
+		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shade_clk), sizeof(h));
+		double tot = 0; for (int k = 0; k < 6; k++) tot += (double)h[k];
+		const char *names[6] = {"loads+normal+slot", "light sample + c0", "bsdf sample c1", "continuation", "reserve", "writes"};
+		if (tot > 0) for (int k = 0; k < 6; k++) std::fprintf(stderr, "[shade clk] %-20s %5.1f %%\n", names[k], 100.0 * h[k] / tot);
+	}
+#endif
 	if (rs.impl) {
 		Impl &im = *static_cast<Impl *>(rs.impl);
 		free_queues(im);
