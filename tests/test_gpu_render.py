@@ -134,8 +134,14 @@ def test_untraced_connection_rays_change_nothing(ctx, cornell_dir, monkeypatch, 
     must be the same (sums reordered), and only the ray count may differ.  NaiveBDPT does the same for its t = 0 strategy
     (any light counts there, renderer.cpp:675-676; its counters count connection slots, traced or not).  The same switch
     also queues the camera rays that cannot touch the scene's bounding box (the wide frame sees past the box on both sides)."""
-    for obj_name, nx, ny in (("cornell_box_triangulated.obj", 128, 96), ("cornell_box.obj", 128, 96), ("cornell_box_triangulated.obj", 240, 64)):
+    for obj_name, nx, ny, variant in (("cornell_box_triangulated.obj", 128, 96, "plain"), ("cornell_box.obj", 128, 96, "plain"),
+                                      ("cornell_box_triangulated.obj", 240, 64, "plain"), ("cornell_box_triangulated.obj", 160, 90, "specular"),
+                                      ("cornell_box_triangulated.obj", 160, 90, "graphs")):
         mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, nx, ny, obj_name=obj_name)
+        if variant == "specular":
+            records = specular_records(mesh, records)  # glass, metal, coloured metal: delta lobes, zero and infinite factors
+        elif variant == "graphs":
+            records = graph_records(mesh, records)     # per-hit albedo and light colour programs
         ctx.upload_mesh(mesh)
         ctx.upload_materials(records)
         ctx.set_camera(cam)
