@@ -126,15 +126,18 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	if (int rc = finish_pending_paths(ctx)) return rc;
 	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize")) return RT_ERR_HIP;
+	// whatever happens below, the old scene is gone: a render in progress has nothing left to continue with
 	ctx->free_geometry();
 	ctx->has_materials = false;
+	ctx->render.begun = false;
 	std::string err;
 	if (!ctx->host.build(*mesh, err)) return set_err(ctx, RT_ERR_MESH, err);
 	const HostScene &hs = ctx->host;
 	const uint64_t nt = hs.n_tris;
 	int builder = ctx->builder;
 	if (const char *s = std::getenv("MI355RT_BUILDER")) builder = std::strcmp(s, "device") == 0 ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
-	if (builder == RT_BUILDER_AUTO) builder = nt > 2000000 ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
+	const bool auto_chosen = builder == RT_BUILDER_AUTO;
+	if (auto_chosen) builder = nt > 2000000 ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
 	if (nt < 2) builder = RT_BUILDER_HOST_SAH; // the radix tree needs two leaves
 	// fp64 triangle data: v0 + face normal, v1 + v2.  The host builder writes the 128-byte leaf-ordered records of device_scene.h
 	// itself; the device builder takes the two halves in fan order and gathers the records on the GPU.
@@ -184,14 +187,22 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 		if (!ok) {
 			std::string keep = ctx->error;
 			ctx->free_geometry();
-			return set_err(ctx, RT_ERR_HIP, keep);
+			// a tree the Morton builder cannot shape (too deep for the traversal stack, too many coincident centroids in one node)
+			// is not the caller's problem when the caller did not ask for that builder: the host builder takes over
+			if (!auto_chosen) return set_err(ctx, RT_ERR_HIP, keep);
+			builder = RT_BUILDER_HOST_SAH;
 		}
-	} else {
+	}
+	if (builder != RT_BUILDER_DEVICE_LBVH) {
 		BvhBuildOptions opt;
 		if (const char *s = std::getenv("MI355RT_MAX_LEAF")) opt.max_leaf = std::atoi(s);
 		build_bvh(ctx->host, opt, ctx->bvh, ctx->wide);
 		ctx->built_on_device = false;
 		ctx->device_nodes = ctx->wide.nodes.size();
+		if (ctx->wide.depth > kTraceMaxDepth) {
+			ctx->free_geometry();
+			return set_err(ctx, RT_ERR_MESH, "rt_upload_mesh: the tree is deeper than the traversal stack (" + std::to_string(ctx->wide.depth) + " levels, limit " + std::to_string(kTraceMaxDepth) + ")");
+		}
 		const uint32_t stride = triangle_record_stride(nt);
 		ctx->geom.tri_stride = stride;
 		std::vector<double> recs(2 * (size_t)stride * std::max<uint64_t>(nt, 1), 0.0);
@@ -353,6 +364,7 @@ int rt_clear(rt_context *ctx)
 	(void)hipStreamSynchronize(ctx->stream);
 	ctx->free_geometry();
 	ctx->has_materials = false;
+	ctx->render.begun = false; // a render in progress ends with the scene it was rendering
 	ctx->host = HostScene();
 	ctx->bvh = Bvh2();
 	ctx->wide = BvhWide();
@@ -435,6 +447,8 @@ int rt_render_pass(rt_context *ctx, int first_sample, int n_samples)
 {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_render_pass: call rt_render_begin first");
+	// the tables the kernels index (tree, triangles, materials, lights) must be the ones rt_render_begin saw
+	if (!ctx->has_mesh || !ctx->has_materials) return set_err(ctx, RT_ERR_INVALID, "rt_render_pass: the scene was cleared or its materials were refused after rt_render_begin");
 	if (first_sample < 0 || n_samples < 0) return set_err(ctx, RT_ERR_INVALID, "rt_render_pass: negative sample range");
 	if (n_samples == 0) return RT_OK;
 	if (!use_device(ctx)) return RT_ERR_HIP;

@@ -21,6 +21,7 @@
 #include <string>
 #include "bvh_builder.h"
 #include "device_build.h"
+#include "trace.h"
 
 namespace mi355rt {
 
@@ -481,7 +482,7 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	int cur = 0;
 	while (n_in > 0) {
 		depth++;
-		if (depth > 200) { err = "build_bvh_device: tree deeper than 200 levels"; return hipErrorUnknown; }
+		if (depth > kTraceMaxDepth) { err = "build_bvh_device: tree deeper than the traversal stack (" + std::to_string(kTraceMaxDepth) + " levels)"; return hipErrorUnknown; }
 		hipLaunchKernelGGL(k_collapse, dim3((n_in + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, bin, node_boxes, as_leaf, tri_boxes, sorted_tri,
 		                   queue[cur], n_in, queue[cur ^ 1], wide, leaf_tri, ctr);
 		DB_TRY(hipMemcpyAsync(&h_ctr, ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, stream));

@@ -1630,10 +1630,17 @@ static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &ge
 		if (im.conn_any) (void)hipFree(im.conn_any);
 		im.conn_rays = nullptr; im.conn = nullptr; im.conn_hits = nullptr; im.conn_any = nullptr;
 		im.conn_capacity = 0;
-		HIP_TRY(hipMalloc((void **)&im.conn_rays, want * sizeof(rt_ray)));
-		HIP_TRY(hipMalloc((void **)&im.conn, want * sizeof(ConnRec)));
-		HIP_TRY(hipMalloc((void **)&im.conn_hits, want * sizeof(rt_hit)));
-		HIP_TRY(hipMalloc((void **)&im.conn_any, want));
+		hipError_t ge = hipMalloc((void **)&im.conn_rays, want * sizeof(rt_ray));
+		if (ge == hipSuccess) ge = hipMalloc((void **)&im.conn, want * sizeof(ConnRec));
+		if (ge == hipSuccess) ge = hipMalloc((void **)&im.conn_hits, want * sizeof(rt_hit));
+		if (ge == hipSuccess) ge = hipMalloc((void **)&im.conn_any, want);
+		if (ge != hipSuccess) {
+			// the path queues are useless without their connection queues: drop them all, so that the next pass of any
+			// integrator allocates a complete set again instead of launching over null connection buffers
+			free_queues(im);
+			err = std::string("NaiveBDPT connection queues: ") + hipGetErrorString(ge);
+			return ge;
+		}
 		im.conn_capacity = want;
 	}
 	if (total == 0) return hipSuccess;

@@ -4,6 +4,8 @@
 #include "mi355rt.h"
 
 namespace mi355rt {
+// deepest tree the traversal kernels walk (entries of the per-lane stack when it lives in scratch); builders refuse deeper trees
+constexpr uint32_t kTraceMaxDepth = 96;
 // closest hit over n device-resident rays; d_t64 may be null.  When d_n is not null the kernel reads the ray count
 // from it (a count produced by an earlier kernel on the same stream) and n is only an upper bound that sizes the grid.
 hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, hipStream_t stream,

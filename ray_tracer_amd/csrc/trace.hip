@@ -35,7 +35,7 @@ namespace {
 #endif
 constexpr int kBlock = 256;
 constexpr int kLdsStack = TRACE_LDS_STACK; // stack entries (8 bytes) per lane held in LDS: one per tree level
-constexpr int kScratchStack = 96;          // deeper trees (bounded by the builder)
+constexpr int kScratchStack = (int)kTraceMaxDepth; // deeper trees (the builders refuse what does not fit)
 
 struct RayD {
 	double ox, oy, oz, dx, dy, dz, tmin;

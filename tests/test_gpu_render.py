@@ -190,6 +190,50 @@ def test_no_lights_is_refused(ctx, cornell_dir):
         ctx.upload_materials(records[:-1])  # an object without a material, renderer.cpp:29-32
 
 
+def test_render_pass_after_the_scene_changed_is_refused(cornell_dir):
+    """a render that was begun does not survive rt_clear, a new mesh or refused materials: rt_render_pass must answer
+    RT_ERR_INVALID instead of launching kernels over freed or mismatched tables"""
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 32, 32)
+    c = capi.Context(0)
+
+    def begin():
+        c.upload_mesh(mesh)
+        c.upload_materials(records)
+        c.set_camera(cam)
+        c.render_begin(32, 32, 4, 30, capi.ALG_MIS, 1)
+        c.render_pass(0, 1)
+
+    def refused():
+        with pytest.raises(capi.BackendError) as e:
+            c.render_pass(1, 1)
+        assert e.value.code == capi.ERR_INVALID
+
+    begin()
+    c.clear()
+    refused()
+    c.render_sync()  # nothing pending, nothing to fault on
+    begin()
+    c.upload_mesh(mesh)  # new geometry, no materials yet
+    refused()
+    c.upload_materials(records)
+    refused()  # still no rt_render_begin for the new scene
+    begin()
+    with pytest.raises(capi.BackendError):
+        c.upload_materials([dict(r, light_flag=False) for r in records])
+    refused()
+    with pytest.raises(capi.BackendError):  # a malformed mesh (face with two corners) also ends the render
+        begin()
+        bad = dict(mesh, face_begin=np.array([0, 2], dtype=np.uint64), object_begin=np.array([0, 1], dtype=np.uint64))
+        c.upload_mesh(bad)
+    refused()
+    # and the context is still usable
+    begin()
+    c.render_pass(1, 3)
+    c.render_sync()
+    assert np.isfinite(c.download_film()).all() and c.download_film().sum() > 0
+    c.close()
+
+
 def test_cpp_host_renderer_matches_the_python_host(ctx, cornell_dir, tmp_path):
     """ray_tracer_amd/host (C++ mirror of Renderer/obj/NodeMaterial/LensCamera) drives the same library to the same film"""
     import os
