@@ -195,6 +195,13 @@ int rt_clear(rt_context *ctx);
  * Host buffers; t64 (optional, may be NULL) receives rec.t in double, +inf on a miss.
  * Ties in t between different polygons resolve to the lowest fan-triangle index. */
 int rt_trace_closest(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64);
+/* rt_trace_closest for callers that may not allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  Same arguments and results as rt_trace_closest, but the device-side staging of
+ * rays, hits and t64 lives in a file-scope device array of the library (56 MiB per GPU, held from library load to process end)
+ * instead of buffers grown with hipMalloc: the call allocates and frees nothing.  n > RT_STATIC_MAX_RAYS is refused with
+ * RT_ERR_INVALID.  All contexts of one GPU share that GPU's array: calls that overlap on one GPU race (serialise them). */
+#define RT_STATIC_MAX_RAYS (1ull << 20)
+int rt_trace_closest_static(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64);
 /* replaces: world->Occluded(r, t_min, t_max) (hittable.h:34-40, called at renderer.cpp:263). out[i] = 0/1 */
 int rt_trace_any(rt_context *ctx, const rt_ray *rays, uint64_t n, uint8_t *out);
 /* same, on buffers already resident in HBM, enqueued on `stream` (a hipStream_t, NULL = the

@@ -10,13 +10,14 @@ OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NO_LIGHTS, ERR_NO_MATERIAL, ERR_MES
 BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH, BUILDER_AUTO = 0, 1, 2
 MAT_NONE, MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_COLORED_METAL = range(6)
 ALG_NAIVE, ALG_NEE, ALG_MIS, ALG_NAIVE_BDPT, ALG_MIS_BDPT = 0, 1, 2, 3, 4
+STATIC_MAX_RAYS = 1 << 20
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmi355rt.so")
 
 # every symbol include/mi355rt.h declares
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_environment", "rt_upload_materials", "rt_upload_material_graphs", "rt_set_camera", "rt_clear",
-    "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
+    "rt_trace_closest", "rt_trace_closest_static", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
     "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
     "rt_get_stats", "rt_get_bvh2", "rt_filter_bilateral", "rt_filter_bilateral_device", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
 ]
@@ -107,6 +108,7 @@ def load():
     lib.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
     lib.rt_clear.argtypes = [vp]
     lib.rt_trace_closest.argtypes = [vp, vp, u64, vp, vp]
+    lib.rt_trace_closest_static.argtypes = [vp, vp, u64, vp, vp]
     lib.rt_trace_any.argtypes = [vp, vp, u64, vp]
     lib.rt_trace_closest_device.argtypes = [vp, vp, u64, vp, vp, vp]
     lib.rt_trace_any_device.argtypes = [vp, vp, u64, vp, vp]
@@ -244,6 +246,15 @@ class Context:
         hits = np.zeros(n, dtype=HIT_DTYPE)
         t64 = np.zeros(n, dtype=np.float64) if want_t64 else None
         self._check(self.lib.rt_trace_closest(self.h, _ptr(rays), n, _ptr(hits), _ptr(t64)))
+        return (hits, t64) if want_t64 else hits
+
+    def trace_closest_static(self, rays, want_t64=False):
+        """rt_trace_closest_static: the same through the library's static staging array (no allocation; at most STATIC_MAX_RAYS rays)"""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = len(rays)
+        hits = np.zeros(n, dtype=HIT_DTYPE)
+        t64 = np.zeros(n, dtype=np.float64) if want_t64 else None
+        self._check(self.lib.rt_trace_closest_static(self.h, _ptr(rays), n, _ptr(hits), _ptr(t64)))
         return (hits, t64) if want_t64 else hits
 
     def trace_any(self, rays):

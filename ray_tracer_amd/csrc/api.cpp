@@ -89,6 +89,14 @@ int rt_create(int device, rt_context **out)
 		delete ctx;
 		return set_err(nullptr, RT_ERR_HIP, msg);
 	}
+	// the allocation-free entry point's staging: address of this device's copy of the static array (device is current here)
+	StaticStage stage;
+	if ((e = static_stage(device, stage)) != hipSuccess) {
+		std::string msg = std::string("rt_create: hipGetSymbolAddress(static staging): ") + hipGetErrorString(e);
+		(void)hipStreamDestroy(ctx->stream);
+		delete ctx;
+		return set_err(nullptr, RT_ERR_HIP, msg);
+	}
 	*out = ctx;
 	return RT_OK;
 }
@@ -409,6 +417,27 @@ int rt_trace_closest(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hi
 	if (rc != RT_OK) return rc;
 	if (ctx->fail_hip(hipMemcpyAsync(hits, ctx->d_stage_out, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream), "D2H hits")) return RT_ERR_HIP;
 	if (t64 && ctx->fail_hip(hipMemcpyAsync(t64, ctx->d_stage_t64, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "D2H t64")) return RT_ERR_HIP;
+	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "closest-hit kernel")) return RT_ERR_HIP;
+	return RT_OK;
+}
+
+int rt_trace_closest_static(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64)
+{
+	if (!ctx || (n && (!rays || !hits))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_static: NULL argument");
+	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_static: no mesh uploaded");
+	if (n > kStaticRays)
+		return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_static: " + std::to_string(n) + " rays exceed the static staging area of " +
+		                                     std::to_string(kStaticRays) + " rays (RT_STATIC_MAX_RAYS); split the batch or use rt_trace_closest");
+	if (n == 0) return RT_OK;
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	StaticStage st;
+	if (ctx->fail_hip(static_stage(ctx->device, st), "static staging")) return RT_ERR_HIP;
+	// nothing in the staging area has to start from zero: the kernel writes hits[i] and t64[i] for every i < n, and only those are copied back
+	if (ctx->fail_hip(hipMemcpyAsync(st.rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream), "H2D rays")) return RT_ERR_HIP;
+	int rc = rt_trace_closest_device(ctx, st.rays, n, st.hits, t64 ? st.t64 : nullptr, nullptr);
+	if (rc != RT_OK) return rc;
+	if (ctx->fail_hip(hipMemcpyAsync(hits, st.hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream), "D2H hits")) return RT_ERR_HIP;
+	if (t64 && ctx->fail_hip(hipMemcpyAsync(t64, st.t64, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "D2H t64")) return RT_ERR_HIP;
 	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "closest-hit kernel")) return RT_ERR_HIP;
 	return RT_OK;
 }

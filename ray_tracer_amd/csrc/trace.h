@@ -13,4 +13,11 @@ hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint6
 // any hit: d_out[i] = 1 when some triangle is hit inside [tmin, tmax]
 hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, uint8_t *d_out, hipStream_t stream,
                             const uint32_t *d_n = nullptr);
+
+// Staging memory that exists without any allocation: a file-scope device array of the traversal code object, one copy per GPU,
+// sized for kStaticRays rays with their hits and fp64 distances.  static_stage() returns the address of the calling device's copy
+// (looked up once per device, with that device current) and must be called with `device` current.
+constexpr uint64_t kStaticRays = 1ull << 20;
+struct StaticStage { rt_ray *rays; rt_hit *hits; double *t64; };
+hipError_t static_stage(int device, StaticStage &out);
 } // namespace mi355rt

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cstdint>
+#include <mutex>
 #include "device_scene.h"
 #include "trace.h"
 
@@ -527,6 +528,38 @@ hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t 
 	else
 		hipLaunchKernelGGL((k_trace<false, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out, d_n);
 	return hipGetLastError();
+}
+
+// ---- staging that needs no allocation (rt_trace_closest_static)
+namespace {
+constexpr size_t kStaticRayBytes = kStaticRays * sizeof(rt_ray), kStaticHitBytes = kStaticRays * sizeof(rt_hit), kStaticT64Bytes = kStaticRays * sizeof(double);
+// 56 MiB per GPU, held from the moment the library is loaded on that GPU until the process ends
+static __device__ __align__(256) unsigned char scratch[kStaticRayBytes + kStaticHitBytes + kStaticT64Bytes];
+constexpr int kMaxDevices = 64;
+unsigned char *g_scratch_ptr[kMaxDevices]; // per device: every GPU holds its own copy of the array at its own address
+std::mutex g_scratch_mutex;
+} // namespace
+
+hipError_t static_stage(int device, StaticStage &out)
+{
+	if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+	unsigned char *p = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(g_scratch_mutex);
+		if (!g_scratch_ptr[device]) {
+			// the array's name is a host-side handle, not a device address: ask the runtime where this device keeps it
+			void *sym = nullptr;
+			hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+			if (e != hipSuccess) return e;
+			if (!sym) return hipErrorInvalidSymbol;
+			g_scratch_ptr[device] = static_cast<unsigned char *>(sym);
+		}
+		p = g_scratch_ptr[device];
+	}
+	out.rays = reinterpret_cast<rt_ray *>(p);
+	out.hits = reinterpret_cast<rt_hit *>(p + kStaticRayBytes);
+	out.t64 = reinterpret_cast<double *>(p + kStaticRayBytes + kStaticHitBytes);
+	return hipSuccess;
 }
 
 } // namespace mi355rt
