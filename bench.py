@@ -179,9 +179,24 @@ def main():
                     help="integrator of the timed workload (the headline metric is quoted on mis)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and never
+        # touches the GPU itself; the ranks re-enter main() with RANK / WORLD_SIZE set by torch.distributed.run
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the job has %d rank(s): start it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run with --nproc-per-node N" % (args.gpus, world))
     import torch
     import torch.distributed as dist
     from ray_tracer_amd import capi, parallel, scenes, synth
@@ -243,10 +258,16 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_stop()
+    ranks_in = 1
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # n_gpus is what took part, not what was asked for: every rank that went through the film all-reduce adds one
+        one = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(one)
+        ranks_in = int(round(float(one.item())))
+        assert ranks_in == args.gpus, "%d ranks entered the all-reduce, --gpus says %d" % (ranks_in, args.gpus)
     stats = ctx.stats()
     film_mean = float(film.sum().item()) / (nx * ny) * (ns_total / (per_rank * world))
     ok = bool(torch.isfinite(film).all().item())
@@ -293,13 +314,13 @@ def main():
                                  "soup under aux (frac_of_random_line_rate)")
         line = {
             "metric": "spp/s at 1080p (Cornell box, NEE+MIS wavefront integrator); the incoherent closest-hit Mrays/s half of the metric is under aux",
-            "value": args.steps * spp * world / dt, "unit": "spp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": args.steps * spp * world / dt, "unit": "spp/s", "n_gpus": ranks_in, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "dtype_detail": "f64 triangle test (the reference's arithmetic), f32 conservative box tests and shading", "data": "synthetic",
+            "dtype": "f32 (f64 triangle test)", "dtype_detail": "f32 conservative box tests, shading and film; the triangle test is the reference's f64 arithmetic", "data": "synthetic",
             "config": {"workload": "Cornell box (example/cornell_box_triangulated.obj + materials.json) %dx%d, %s, 30 spectral bands, "
                                    "%d spp per step, %d spp timed per GPU" % (nx, ny, {"mis": "NEE+MIS", "nee": "NEE", "naive": "naive path tracing",
                                                                                       "bdpt": "NaiveBDPT"}[args.algorithm], spp, args.steps * spp),
-                       "parallelism": "samples sharded over %d GPU(s), one RCCL all-reduce of the film" % world},
+                       "parallelism": "samples sharded over %d GPU(s), one %s all-reduce of the film" % (world, "gloo (rehearsal: all ranks on device 0)" if rehearsal else "RCCL")},
             "msamples_per_s": args.steps * spp * world * nx * ny / dt / 1e6,
             "rays_per_sample": (stats["closest_rays"] + stats["any_rays"]) / max(stats["camera_samples"], 1),
             "kernels_ms": {name: v["ms"] for name, v in prof.items()},

@@ -1,0 +1,80 @@
+"""The N>1 product path on one GPU: two ranks (both on device 0, gloo standing in for RCCL) render their sample ranges through the C ABI
+into caller-owned films (torch tensors handed to rt_render_begin), sum them with parallel.reduce_film, and must reproduce the film a
+single context renders for all samples.  This is the hand-off bench.py uses for --gpus N (its BENCH_REHEARSAL=1 mode)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from ray_tracer_amd import capi, scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ray_tracer_amd import capi, scenes
+from ray_tracer_amd.parallel import sample_range, reduce_film
+nx, ny, ns, seed = (int(a) for a in sys.argv[3:7])
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+ctx = capi.Context(0)
+mesh, records, cam = scenes.cornell(nx, ny)
+ctx.upload_mesh(mesh); ctx.upload_materials(records); ctx.set_camera(cam)
+film = torch.zeros(nx * ny * capi.NBINS, dtype=torch.float32, device="cuda")
+ctx.render_begin(nx, ny, ns, 30, capi.ALG_MIS, seed, film.data_ptr())
+first, count = sample_range(rank, world, ns)
+# in passes of two, so that paths handed from one pass to the next take part
+for s in range(first, first + count, 2):
+    ctx.render_pass(s, min(2, first + count - s))
+ctx.render_sync()
+torch.cuda.synchronize()
+own = float(film.sum().item())
+reduce_film(film)
+torch.cuda.synchronize()
+sums = [None] * world
+dist.all_gather_object(sums, (first, count, own, ctx.stats()["camera_samples"]))
+if rank == 0:
+    np.save(sys.argv[2], film.cpu().numpy())
+    import json
+    json.dump(sums, open(sys.argv[2] + ".json", "w"))
+ctx.close()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_on_one_gpu_sum_to_the_single_context_film(tmp_path):
+    nx, ny, ns, seed = 160, 90, 7, 31
+    worker = tmp_path / "worker.py"
+    worker.write_text(WORKER)
+    out = tmp_path / "film.npy"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29573", str(worker), ROOT, str(out), str(nx), str(ny), str(ns), str(seed)]
+    subprocess.run(cmd, check=True, env=env, timeout=280, cwd=str(tmp_path))
+    got = np.load(out).astype(np.float64).reshape(nx * ny, capi.NBINS)
+    per_rank = json.load(open(str(out) + ".json"))
+    assert [(f, c) for f, c, _, _ in per_rank] == [(0, 4), (4, 3)]          # the ranks' sample blocks tile 0..ns
+    assert [n for _, _, _, n in per_rank] == [4 * nx * ny, 3 * nx * ny]      # and each rendered exactly its own
+    ctx = capi.Context(0)
+    mesh, records, cam = scenes.cornell(nx, ny)
+    ctx.upload_mesh(mesh)
+    ctx.upload_materials(records)
+    ctx.set_camera(cam)
+    ctx.render_begin(nx, ny, ns, 30, capi.ALG_MIS, seed)
+    ctx.render_pass(0, ns)
+    ctx.render_sync()
+    whole = ctx.download_film()
+    ctx.close()
+    assert whole.sum() > 0 and np.isfinite(got).all()
+    assert abs(sum(o for _, _, o, _ in per_rank) - whole.sum()) <= 1e-5 * whole.sum()
+    # fp32 atomics add in a different order in every run: equality up to rounding of the sums
+    assert np.allclose(got, whole, rtol=1e-4, atol=1e-8)
