@@ -12,7 +12,8 @@ MAT_NONE, MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_
 ALG_NAIVE, ALG_NEE, ALG_MIS, ALG_NAIVE_BDPT, ALG_MIS_BDPT = 0, 1, 2, 3, 4
 STATIC_MAX_RAYS = 1 << 20
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmi355rt.so")
+# MI355RT_LIB names another build of the same library (kernel experiments: tools/bench_trace.py); there is still no fallback
+LIB_PATH = os.environ.get("MI355RT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmi355rt.so")
 
 # every symbol include/mi355rt.h declares
 EXPORTS = [

@@ -15,7 +15,10 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
+#include <limits>
 #include <string>
+#include <utility>
 #include <vector>
 #include "render.h"
 #include "trace.h"
@@ -153,6 +156,9 @@ struct Impl {
 	// paths of the previous batch that were still alive when it was cut short (see run_batch): they sit at the front of rays[carry_cur]
 	uint64_t carry_count = 0;
 	int carry_cur = 0;
+	// pixels some camera ray of which may touch the scene (see live_pixel_list); null: every pixel
+	uint32_t *live_pixels = nullptr;
+	uint64_t n_live = 0;
 	// NaiveBDPT: per-sample records, subpath vertices, connection slot counts and offsets
 	void *bdpt_samples = nullptr, *bdpt_verts = nullptr, *bdpt_scan_tmp = nullptr;
 	uint32_t *bdpt_counts = nullptr, *bdpt_offsets = nullptr;
@@ -573,12 +579,16 @@ __device__ __forceinline__ bool ray_may_reach(float4 b0, float4 b1, f3 o, f3 d)
 // one camera sample: the ray and the path state it starts with
 template <bool BDPT>
 __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBand *__restrict__ bands, uint32_t n_bands, int nx, int ny, int ns,
-                                              int first_sample, uint64_t seed, float tmin, uint64_t idx, BdptSample *__restrict__ samples,
-                                              rt_ray &r, PathState &st)
+                                              int first_sample, int n_samples, uint64_t seed, float tmin, uint64_t idx, BdptSample *__restrict__ samples,
+                                              rt_ray &r, PathState &st, const uint32_t *__restrict__ live = nullptr)
 {
 	// a batch holds fewer than 2^31 samples (render_pass): 32-bit divisions, a fraction of the cost of 64-bit ones
-	const uint32_t npix = (uint32_t)nx * (uint32_t)ny, idx32 = (uint32_t)idx;
-	const uint32_t sample_off = idx32 / npix, pixel = idx32 - sample_off * npix;
+	// The samples of one pixel are neighbours in the queue (index = pixel * n_samples + sample): a wave then adds to a few
+	// neighbouring film pixels instead of 64 different ones (scattered float atomics cost one memory request per 64-byte
+	// segment touched), and its camera rays start out coherent.
+	const uint32_t idx32 = (uint32_t)idx;
+	const uint32_t slot = idx32 / (uint32_t)n_samples, sample_off = idx32 - slot * (uint32_t)n_samples;
+	const uint32_t pixel = live ? live[slot] : slot; // only the pixels that can see the scene are generated at all
 	const int sample = first_sample + (int)sample_off;
 	const int i = (int)(pixel / (uint32_t)ny), j = (int)(pixel - (uint32_t)i * (uint32_t)ny);
 	uint64_t rng = rng_seed(seed, pixel, (uint64_t)sample);
@@ -622,7 +632,7 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBan
 // rays and state point at the first free queue slot (paths carried over from the previous batch sit in front of it)
 template <bool BDPT>
 __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBand *__restrict__ bands, uint32_t n_bands,
-                                                     int nx, int ny, int ns, int first_sample, uint64_t n_paths,
+                                                     int nx, int ny, int ns, int first_sample, int n_samples, uint64_t n_paths,
                                                      uint64_t seed, float tmin, rt_ray *__restrict__ rays,
                                                      PathState *__restrict__ state, BdptSample *__restrict__ samples)
 {
@@ -630,7 +640,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBan
 	if (idx >= n_paths) return;
 	rt_ray r;
 	PathState st;
-	camera_sample<BDPT>(cam, bands, n_bands, nx, ny, ns, first_sample, seed, tmin, idx, samples, r, st);
+	camera_sample<BDPT>(cam, bands, n_bands, nx, ny, ns, first_sample, n_samples, seed, tmin, idx, samples, r, st);
 	rays[idx] = r;
 	state[idx] = st;
 }
@@ -650,10 +660,10 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBan
 constexpr int kGenBlock = GEN_BLOCK, kGenPer = GEN_PER;
 template <bool BDPT>
 __global__ void __launch_bounds__(kGenBlock) k_generate_cull(DevCamera cam, const DevBand *__restrict__ bands, uint32_t n_bands,
-                                                             int nx, int ny, int ns, int first_sample, uint64_t n_paths,
+                                                             int nx, int ny, int ns, int first_sample, int n_samples, uint64_t n_paths,
                                                              uint64_t seed, float tmin, rt_ray *__restrict__ rays,
                                                              PathState *__restrict__ state, BdptSample *__restrict__ samples, float4 box_lo,
-                                                             float4 box_hi, unsigned long long *__restrict__ tails)
+                                                             float4 box_hi, unsigned long long *__restrict__ tails, const uint32_t *__restrict__ live)
 {
 	__shared__ uint32_t s_wave[kGenBlock / 64];
 	__shared__ uint32_t s_base;
@@ -668,7 +678,7 @@ __global__ void __launch_bounds__(kGenBlock) k_generate_cull(DevCamera cam, cons
 		const uint64_t idx = ((uint64_t)blockIdx.x * kGenPer + j) * kGenBlock + threadIdx.x;
 		bool keep = false;
 		if (idx < n_paths) {
-			camera_sample<false>(cam, bands, n_bands, nx, ny, ns, first_sample, seed, tmin, idx, nullptr, r[j], st[j]);
+			camera_sample<false>(cam, bands, n_bands, nx, ny, ns, first_sample, n_samples, seed, tmin, idx, nullptr, r[j], st[j], live);
 			keep = ray_may_reach(box_lo, box_hi, F3(r[j].ox, r[j].oy, r[j].oz), F3(r[j].dx, r[j].dy, r[j].dz));
 		}
 		kept[j] = __ballot(keep);
@@ -1259,6 +1269,65 @@ hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const
 	return hipSuccess;
 }
 
+// The pixels some camera ray of which may touch the scene's bounding box, in pixel order.  For one pixel, every quantity of
+// camera_sample is an interval: u, v span the pixel (the jitter), the lens offset spans the whole lens square, and the band
+// picks one of the lens's image distances; interval arithmetic over the slab test then either proves that no such ray reaches
+// the box, or the pixel stays.  Intervals and the box are widened far beyond the kernel's fp32 rounding (1e-5 relative
+// against ~1e-7), and a pixel that stays is still tested ray by ray on the device, so the list only has to err towards keeping.
+static void live_pixel_list(const DevCamera &dc, const std::vector<DevBand> &bands, int nx, int ny, float4 box_lo, float4 box_hi, std::vector<uint32_t> &out)
+{
+	struct Iv { double lo, hi; };
+	auto scale = [](Iv a, double k) { return k >= 0.0 ? Iv{a.lo * k, a.hi * k} : Iv{a.hi * k, a.lo * k}; };
+	auto widen = [](Iv a, double by) { return Iv{a.lo - by, a.hi + by}; };
+	std::vector<std::pair<double, bool>> variants; // distinct (image distance ratio, direction sign) pairs over the bands
+	for (const DevBand &b : bands) {
+		std::pair<double, bool> v((double)b.neg_a_over_d, b.a_positive != 0.0f);
+		bool seen = false;
+		for (auto &w : variants) seen = seen || w == v;
+		if (!seen) variants.push_back(v);
+	}
+	const double inf = std::numeric_limits<double>::infinity();
+	const double big = std::max({(double)box_lo.w, std::fabs((double)dc.origin[0]), std::fabs((double)dc.origin[1]), std::fabs((double)dc.origin[2])});
+	const double pad = 4e-4 * big + 1e-30;
+	const double blo[3] = {box_lo.x - pad, box_lo.y - pad, box_lo.z - pad}, bhi[3] = {box_hi.x + pad, box_hi.y + pad, box_hi.z + pad};
+	double lens_r[3]; // |lens offset| per axis is at most this
+	for (int c = 0; c < 3; c++) lens_r[c] = 1.00001 * (double)dc.half_aperture * (std::fabs((double)dc.horizontal[c]) + std::fabs((double)dc.vertical[c]));
+	out.clear();
+	for (int i = 0; i < nx; i++) {
+		const Iv u = {((double)i - 1e-3) / nx, ((double)i + 1.0 + 1e-3) / nx};
+		for (int j = 0; j < ny; j++) {
+			const Iv v = {((double)j - 1e-3) / ny, ((double)j + 1.0 + 1e-3) / ny};
+			Iv isp[3], org[3];
+			for (int c = 0; c < 3; c++) {
+				const Iv a = scale(u, (double)dc.horizontal[c]), b = scale(v, (double)dc.vertical[c]);
+				const double mag = std::fabs((double)dc.llc_rel[c]) + std::fabs((double)dc.horizontal[c]) + std::fabs((double)dc.vertical[c]);
+				isp[c] = widen(Iv{dc.llc_rel[c] + a.lo + b.lo, dc.llc_rel[c] + a.hi + b.hi}, 1e-5 * mag);
+				org[c] = widen(Iv{(double)dc.origin[c], (double)dc.origin[c]}, lens_r[c] + 1e-5 * std::fabs((double)dc.origin[c]));
+			}
+			bool live = false;
+			for (const auto &var : variants) {
+				double near_lo = -inf, far_hi = inf; // largest lower bound of an entry distance, smallest upper bound of an exit distance
+				for (int c = 0; c < 3; c++) {
+					Iv d = widen(scale(isp[c], var.first), lens_r[c]); // direction before normalisation: k * isp - lens
+					d = widen(d, 1e-5 * std::max(std::fabs(d.lo), std::fabs(d.hi)));
+					if (!var.second) d = Iv{-d.hi, -d.lo};
+					if (d.lo <= 0.0 && d.hi >= 0.0) continue; // the ray may run along this slab: no bound from this axis
+					// entry plane: the lower face for d > 0, the upper face for d < 0; numerators as intervals over the origin
+					const Iv n_in = d.lo > 0.0 ? Iv{blo[c] - org[c].hi, blo[c] - org[c].lo} : Iv{bhi[c] - org[c].hi, bhi[c] - org[c].lo};
+					const Iv n_out = d.lo > 0.0 ? Iv{bhi[c] - org[c].hi, bhi[c] - org[c].lo} : Iv{blo[c] - org[c].hi, blo[c] - org[c].lo};
+					const double q_in = std::min({n_in.lo / d.lo, n_in.lo / d.hi, n_in.hi / d.lo, n_in.hi / d.hi});
+					const double q_out = std::max({n_out.lo / d.lo, n_out.lo / d.hi, n_out.hi / d.lo, n_out.hi / d.hi});
+					near_lo = std::max(near_lo, q_in);
+					far_hi = std::min(far_hi, q_out);
+				}
+				const double slack = 1e-5 * std::max(std::fabs(near_lo) < inf ? std::fabs(near_lo) : 0.0, std::fabs(far_hi) < inf ? std::fabs(far_hi) : 0.0);
+				if (!(near_lo > far_hi + slack) && !(far_hi < -slack)) { live = true; break; }
+			}
+			if (live) out.push_back((uint32_t)(i * ny + j));
+		}
+	}
+}
+
 hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, int ns, int spectral_samples, int algorithm,
                         uint64_t seed, void *d_film, hipStream_t stream, std::string &err)
 {
@@ -1322,6 +1391,12 @@ hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, i
 		const char *all = std::getenv("MI355RT_TRACE_ALL_CONNECTIONS");
 		im.cull_connections = !(all && all[0] == '1');
 	}
+	{
+		std::vector<uint32_t> live;
+		live_pixel_list(dc, bands, nx, ny, im.scene_lo, im.scene_hi, live);
+		im.n_live = live.size();
+		HIP_TRY(upload(im.live_pixels, live, stream));
+	}
 	rs.begun = true;
 	return hipStreamSynchronize(stream);
 }
@@ -1353,8 +1428,11 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 	// stay where they are and the next batch generates its camera rays behind them (a path carries its bounce number, pixel
 	// and random stream, so paths of different depth mix freely).  render_flush runs what is left to completion; everything
 	// that reads the film or the counters calls it first.
-	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_paths = flush ? 0 : npix * (uint64_t)n_samples;
-	const uint64_t carry_limit = (flush || rs.capture_buf) ? 0 : n_paths / kCarryDivisor;
+	// camera rays that cannot touch the scene are dropped at the source unless a miss contributes (the naive integrator's environment):
+	// pixels no ray of which can reach the scene's box are not generated at all, the others are tested ray by ray
+	const bool cull_camera = !flush && im.cull_connections && !rs.capture_buf && !(ALG == RT_ALG_NAIVE && im.env != nullptr);
+	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_paths = flush ? 0 : (cull_camera ? im.n_live : npix) * (uint64_t)n_samples;
+	const uint64_t carry_limit = (flush || rs.capture_buf) ? 0 : npix * (uint64_t)n_samples / kCarryDivisor;
 	const uint64_t carried = im.carry_count;
 	int cur = carried ? im.carry_cur : 0;
 	im.carry_count = 0;
@@ -1370,8 +1448,6 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 		if (rs.capture_count_out) *rs.capture_count_out = rs.capture_count;
 		return e;
 	};
-	// camera rays that cannot touch the scene are dropped at the source unless a miss contributes (the naive integrator's environment)
-	const bool cull_camera = n_paths && im.cull_connections && !rs.capture_buf && !(ALG == RT_ALG_NAIVE && im.env != nullptr);
 	// Queue sizes stay on the device: every kernel of bounce b reads its item count from the slot the previous
 	// kernel wrote, and the host only sizes grids from upper bounds (paths can only die; at most two connection
 	// rays per path).  Counts are copied back asynchronously; the host runs at most two bounces ahead of the
@@ -1388,18 +1464,18 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 			if (cull_camera) {
 				const unsigned cull_blocks = (unsigned)((n_paths + kGenBlock * kGenPer - 1) / (kGenBlock * kGenPer));
 				hipLaunchKernelGGL(k_generate_cull<false>, dim3(cull_blocks), dim3(kGenBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns,
-				                   first_sample, n_paths, rs.seed, tmin, im.rays[cur], im.state[cur], (BdptSample *)nullptr, im.scene_lo, im.scene_hi,
-				                   &im.counters[0].tails);
+				                   first_sample, n_samples, n_paths, rs.seed, tmin, im.rays[cur], im.state[cur], (BdptSample *)nullptr, im.scene_lo, im.scene_hi,
+				                   &im.counters[0].tails, im.live_pixels);
 				// the queue length is what the kernel left in the counter; the host keeps its upper bound
 				HIP_TRY(hipMemcpyAsync(&im.h_counters[0], &im.counters[0], sizeof(Counters), hipMemcpyDeviceToHost, stream));
 			} else {
 				hipLaunchKernelGGL(k_generate<false>, dim3(blocks), dim3(kBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns,
-				                   first_sample, n_paths, rs.seed, tmin, im.rays[cur] + carried, im.state[cur] + carried, (BdptSample *)nullptr);
+				                   first_sample, n_samples, n_paths, rs.seed, tmin, im.rays[cur] + carried, im.state[cur] + carried, (BdptSample *)nullptr);
 			}
 			prof.end(stream);
 			HIP_TRY(hipGetLastError());
-			rs.camera_samples += n_paths;
 		}
+		if (first_round && !flush) rs.camera_samples += npix * (uint64_t)n_samples; // the culled ones were samples too
 		first_round = false;
 		uint64_t bound = entering;
 		int known = 0, b = 0;
@@ -1521,18 +1597,19 @@ static hipError_t ensure_bdpt(Impl &im, uint64_t cap, hipStream_t stream, std::s
 // one batch of NaiveBDPT samples (see render_bdpt.inc for the stages)
 static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err)
 {
-	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_generated = npix * (uint64_t)n_samples;
+	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_generated = (im.cull_connections ? im.n_live : npix) * (uint64_t)n_samples;
 	const DeviceShade sh = make_shade(im);
 	Profiler nop, &prof = rs.profiler ? *rs.profiler : nop;
 	BdptSample *samples = static_cast<BdptSample *>(im.bdpt_samples);
 	BdptVertex *verts = static_cast<BdptVertex *>(im.bdpt_verts);
+	if (n_generated == 0) { rs.camera_samples += npix * (uint64_t)n_samples; return hipSuccess; } // no pixel sees the scene
 	uint64_t n_paths = n_generated; // samples that take part: all, or those whose camera ray can touch the scene
 	prof.begin(Profiler::GENERATE, n_generated, stream);
 	if (im.cull_connections) {
 		HIP_TRY(hipMemsetAsync(im.counters, 0, sizeof(Counters), stream));
 		const unsigned cull_blocks = (unsigned)((n_generated + kGenBlock * kGenPer - 1) / (kGenBlock * kGenPer));
 		hipLaunchKernelGGL(k_generate_cull<true>, dim3(cull_blocks), dim3(kGenBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns,
-		                   first_sample, n_generated, rs.seed, 0.001f, im.rays[0], im.state[0], samples, im.scene_lo, im.scene_hi, &im.counters[0].tails);
+		                   first_sample, n_samples, n_generated, rs.seed, 0.001f, im.rays[0], im.state[0], samples, im.scene_lo, im.scene_hi, &im.counters[0].tails, im.live_pixels);
 		prof.end(stream);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(&im.h_counters[0], &im.counters[0], sizeof(Counters), hipMemcpyDeviceToHost, stream));
@@ -1540,11 +1617,11 @@ static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &ge
 		n_paths = (uint32_t)im.h_counters[0].tails;
 	} else {
 		hipLaunchKernelGGL(k_generate<true>, dim3((unsigned)((n_generated + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands, im.n_bands,
-		                   rs.nx, rs.ny, rs.ns, first_sample, n_generated, rs.seed, 0.001f, im.rays[0], im.state[0], samples);
+		                   rs.nx, rs.ny, rs.ns, first_sample, n_samples, n_generated, rs.seed, 0.001f, im.rays[0], im.state[0], samples);
 		prof.end(stream);
 		HIP_TRY(hipGetLastError());
 	}
-	rs.camera_samples += n_generated;
+	rs.camera_samples += npix * (uint64_t)n_samples;
 	if (n_paths == 0) return hipSuccess;
 	const uint32_t n = (uint32_t)n_paths;
 	const unsigned blocks_n = (unsigned)((n_paths + kBlock - 1) / kBlock);
@@ -1774,6 +1851,7 @@ void render_free(RenderState &rs)
 		if (im.bands) (void)hipFree(im.bands);
 		if (im.env) (void)hipFree(im.env);
 		if (im.tri_uv) (void)hipFree(im.tri_uv);
+		if (im.live_pixels) (void)hipFree(im.live_pixels);
 		free_graphs(im);
 		free_bdpt(im);
 		if (im.counters) {

@@ -1,0 +1,67 @@
+"""A/B harness for the traversal kernels: closest-hit rate on the Cornell box's own render rays (cache-resident scene) and on the
+1M-triangle soup (memory-bound scene), with a checksum of the results so that variants can be compared for identical answers.
+usage: [MI355RT_LIB=path/to/libmi355rt.so] python tools/bench_trace.py [tag] [--soup10m]"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ray_tracer_amd import capi, scenes, synth
+
+tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else os.environ.get("MI355RT_LIB", "default")
+ctx = capi.Context(0)
+
+
+def rate(rays, reps=5, any_hit=False):
+    m = len(rays)
+    d_rays = torch.from_numpy(np.ascontiguousarray(rays)).cuda()
+    d_hits = torch.empty((m, 4), dtype=torch.int32, device="cuda")
+    d_t64 = torch.empty(m, dtype=torch.float64, device="cuda")
+    d_any = torch.empty(m, dtype=torch.uint8, device="cuda")
+    if any_hit:
+        run = lambda: ctx.trace_any_device(d_rays.data_ptr(), m, d_any.data_ptr())
+    else:
+        run = lambda: ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr(), d_t64.data_ptr())
+    for _ in range(2):
+        run()
+    ctx.render_sync()
+    ctx.profile_start()
+    for _ in range(reps):
+        run()
+    ctx.render_sync()
+    p = ctx.profile_stop()["any" if any_hit else "closest"]
+    h = hashlib.sha1()
+    if any_hit:
+        h.update(d_any.cpu().numpy().tobytes())
+    else:
+        h.update(d_hits.cpu().numpy().tobytes())
+        h.update(d_t64.cpu().numpy().tobytes())
+    return m * reps / (p["ms"] * 1e-3) / 1e9, h.hexdigest()[:12]
+
+
+mesh, records, cam = scenes.cornell(960, 540)
+ctx.upload_mesh(mesh)
+ctx.upload_materials(records)
+ctx.set_camera(cam)
+os.environ["MI355RT_TRACE_ALL_CONNECTIONS"] = "1"  # the capture below must not depend on what the integrator drops
+ctx.render_begin(960, 540, 4, 30, capi.ALG_MIS, 1234)
+finish = ctx.capture_rays(1 << 23)
+ctx.render_pass(0, 4)
+ctx.render_sync()
+rays = finish().copy()
+rays = np.concatenate([rays, rays[::-1], rays])[: 1 << 24]
+g, h = rate(rays)
+ga, ha = rate(rays, any_hit=True)
+out = "%-28s cornell %d rays: closest %.2f Grays/s [%s] any %.2f [%s]" % (tag, len(rays), g, h, ga, ha)
+ctx.upload_mesh(synth.soup(1_000_000, 0.004, seed=12345))
+g, h = rate(synth.incoherent_rays(1 << 24, seed=777))
+out += " | soup1m closest %.3f [%s]" % (g, h)
+if "--soup10m" in sys.argv:
+    ctx.upload_mesh(synth.soup(10_000_000, 0.002, seed=12345))
+    g, h = rate(synth.incoherent_rays(1 << 24, seed=777), reps=3)
+    out += " | soup10m closest %.3f [%s]" % (g, h)
+print(out, flush=True)
+ctx.close()
