@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <cfloat>
+#include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstdint>
@@ -126,6 +127,7 @@ struct Impl {
 	uint32_t *light_faces = nullptr;
 	float4 *light_box = nullptr;
 	bool cull_connections = true;
+	int cull_mask = 7;
 	float4 scene_lo = {0, 0, 0, 0}, scene_hi = {0, 0, 0, 0}; // bounding box of all vertices, rounded outwards (scene_lo.w: largest |coordinate|)
 	DevBand *bands = nullptr;
 	uint32_t n_lights = 0, n_bands = 0;
@@ -868,7 +870,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 							c1.c1 = pdfv / fabsf(gvi.z);
 							c1.band_kind = band | (1u << 16);
 							// counts only if its closest hit is on the chosen light, and not at all with a zero factor
-							want_c1 = !sh.cull_connections || (c1.c0 != 0.0f && ray_may_reach_box(sh, sel, p, sdir));
+							want_c1 = !(sh.cull_connections & 4) || (c1.c0 != 0.0f && ray_may_reach_box(sh, sel, p, sdir));
 						}
 					}
 				}
@@ -880,7 +882,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 				if (ALG == RT_ALG_NAIVE) {
 					if (respawn) {
 						st.beta *= ratio * fabsf(gvi.z);
-						if (!(rng_f32(st.rng) < 0.5f) && (st.beta != 0.0f || !sh.cull_connections)) { // :211-215; a zero throughput ends the path
+						if (!(rng_f32(st.rng) < 0.5f) && (st.beta != 0.0f || !(sh.cull_connections & 2))) { // :211-215; a zero throughput ends the path
 							st.beta /= 0.5f;
 							const f3 nd = l2w(uvw, gvi); // not re-normalised, :217
 							nr.ox = p.x; nr.oy = p.y; nr.oz = p.z; nr.tmin = tmin;
@@ -895,7 +897,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 						st.beta /= (1.0f - prr);
 						// a path whose throughput has become exactly zero (a surface that reflects nothing in this band) can add
 						// nothing any more: it is not continued
-						if (respawn && (st.beta != 0.0f || !sh.cull_connections)) {
+						if (respawn && (st.beta != 0.0f || !(sh.cull_connections & 2))) {
 							const f3 nd = unit(l2w(uvw, gvi));
 							nr.ox = p.x; nr.oy = p.y; nr.oz = p.z; nr.tmin = tmin;
 							nr.dx = nd.x; nr.dy = nd.y; nr.dz = nd.z; nr.tmax = __int_as_float(0x7f800000);
@@ -1079,7 +1081,7 @@ DeviceShade make_shade(const Impl &im)
 	sh.materials = im.materials;
 	sh.light_faces = im.light_faces;
 	sh.light_box = im.light_box;
-	sh.cull_connections = im.cull_connections ? 1 : 0;
+	sh.cull_connections = im.cull_connections ? im.cull_mask : 0;
 	sh.bands = im.bands;
 	sh.n_lights = im.n_lights;
 	sh.n_bands = im.n_bands;
@@ -1390,11 +1392,14 @@ hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, i
 	{ // diagnostic switch for tests: trace the connection rays that cannot reach their light as well
 		const char *all = std::getenv("MI355RT_TRACE_ALL_CONNECTIONS");
 		im.cull_connections = !(all && all[0] == '1');
+		const char *m = std::getenv("MI355RT_CULL_MASK"); // diagnostic: bit 0 camera rays, bit 1 dead paths, bit 2 hopeless connections
+		im.cull_mask = m ? std::atoi(m) : 7;
 	}
 	{
 		std::vector<uint32_t> live;
 		live_pixel_list(dc, bands, nx, ny, im.scene_lo, im.scene_hi, live);
 		im.n_live = live.size();
+		if (std::getenv("MI355RT_DEBUG")) std::fprintf(stderr, "[mi355rt] live pixels %zu of %zu\n", live.size(), (size_t)nx * ny);
 		HIP_TRY(upload(im.live_pixels, live, stream));
 	}
 	rs.begun = true;
@@ -1430,7 +1435,7 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 	// that reads the film or the counters calls it first.
 	// camera rays that cannot touch the scene are dropped at the source unless a miss contributes (the naive integrator's environment):
 	// pixels no ray of which can reach the scene's box are not generated at all, the others are tested ray by ray
-	const bool cull_camera = !flush && im.cull_connections && !rs.capture_buf && !(ALG == RT_ALG_NAIVE && im.env != nullptr);
+	const bool cull_camera = !flush && im.cull_connections && (im.cull_mask & 1) && !rs.capture_buf && !(ALG == RT_ALG_NAIVE && im.env != nullptr);
 	const uint64_t npix = (uint64_t)rs.nx * rs.ny, n_paths = flush ? 0 : (cull_camera ? im.n_live : npix) * (uint64_t)n_samples;
 	const uint64_t carry_limit = (flush || rs.capture_buf) ? 0 : npix * (uint64_t)n_samples / kCarryDivisor;
 	const uint64_t carried = im.carry_count;

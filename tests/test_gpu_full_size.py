@@ -111,3 +111,132 @@ def test_4k_render_runs():
         means[alg] = film.sum() / (nx * ny)
     assert 0.05 < means[capi.ALG_MIS] < 0.09 and 1.3 < means[capi.ALG_NAIVE_BDPT] / means[capi.ALG_MIS] < 2.1
     ctx.close()
+
+
+def _check_against_oracle(ctx, mesh, rays, brute=300):
+    """ids and fp64 t of the GPU on `rays` against the oracle's exact polygon test: walked through the product's own BVH2 for all
+    rays (topology shared, arithmetic independent), and by brute force over every polygon for a sample (nothing shared)"""
+    sc = oracle.Scene(mesh)
+    nodes, tri_index = ctx.bvh2()
+    poly, tri, t, _, _ = sc.trace_bvh2(nodes, tri_index, rays, nthreads=16)
+    hits, t64 = ctx.trace_closest(rays, want_t64=True)
+    gp = hits["prim"].astype(np.int64)
+    gp[hits["prim"] == capi.MISS] = -1
+    assert np.array_equal(t64, t)
+    assert (gp != poly).sum() <= 2  # exact ties in t between neighbouring polygons may resolve differently
+    sub = np.random.default_rng(5).choice(len(rays), brute, replace=False)
+    bp, _, bt = sc.trace_closest(rays[sub], oracle.MODE_LIST_LOWEST, nthreads=16)
+    assert np.array_equal(t64[sub], bt) and (gp[sub] != bp).sum() <= 1
+    return float((gp >= 0).mean())
+
+
+def _film_with_and_without_culling(ctx, nx, ny, ns, seed):
+    ctx.render_begin(nx, ny, ns, 30, capi.ALG_MIS, seed)
+    ctx.render_pass(0, ns)
+    ctx.render_sync()
+    film, st = ctx.download_film(), ctx.stats()
+    os.environ["MI355RT_TRACE_ALL_CONNECTIONS"] = "1"
+    try:
+        ctx.render_begin(nx, ny, ns, 30, capi.ALG_MIS, seed)
+        ctx.render_pass(0, ns)
+        ctx.render_sync()
+        film_all, st_all = ctx.download_film(), ctx.stats()
+    finally:
+        del os.environ["MI355RT_TRACE_ALL_CONNECTIONS"]
+    assert np.isfinite(film).all() and film.min() >= 0.0 and film.sum() > 0.0
+    assert st["camera_samples"] == st_all["camera_samples"] == nx * ny * ns
+    assert st_all["closest_rays"] > st["closest_rays"]
+    assert np.allclose(film, film_all, rtol=1e-4, atol=1e-8)
+    return film, st
+
+
+def test_scan_sized_ply_object_full_hd(tmp_path):
+    """The Cornell box with an 870 k-triangle PLY object (a procedural stand-in for a scanned model: none is available offline),
+    written to disk and read back through the PLY reader, once of glass and once of gold, 1920x1080 NEE+MIS"""
+    from ray_tracer_amd import scene_io
+    v, faces = synth.blob(660, 660, (0.0, -0.45, 0.0), 0.4)
+    path = str(tmp_path / "blob.ply")
+    scene_io.write_ply(path, v, faces)
+    p = scene_io.Ply()
+    assert p.Load(path) and len(p.face_begin) - 1 == len(faces) == 869880
+    nx, ny = 1920, 1080
+    mesh, records, cam = scenes.cornell(nx, ny)
+    mesh = p.to_mesh("blob", "auto", into=mesh)
+    one = np.ones(30)
+    lam = 405.0 + 10.0 * np.arange(30)
+    glass = {"type": capi.MAT_DIELECTRIC, "light_flag": 0, "a": 1.5 * one, "b": 0.95 * one}
+    gold = {"type": capi.MAT_CONDUCTOR, "light_flag": 0, "a": np.interp(lam, [400, 500, 550, 700], [1.45, 0.95, 0.35, 0.13]),
+            "b": np.interp(lam, [400, 500, 550, 700], [1.95, 1.85, 2.60, 3.90])}
+    ctx = capi.Context(0)
+    ctx.set_builder(capi.BUILDER_HOST_SAH)
+    ctx.upload_mesh(mesh)
+    st = ctx.stats()
+    assert st["n_triangles"] == 869880 + 972 and st["n_objects"] == 8
+    ctx.set_camera(cam)
+    means = {}
+    for name, rec in (("glass", glass), ("gold", gold)):
+        ctx.upload_materials(list(records) + [rec])
+        film, _ = _film_with_and_without_culling(ctx, nx, ny, 4, 77)
+        means[name] = film.sum() / (nx * ny)
+    assert 0.03 < means["glass"] < 0.12 and 0.03 < means["gold"] < 0.12
+    # the rays of a render of this scene (all bounces, connection rays included), at a tenth of the resolution
+    _, _, cam_s = scenes.cornell(nx // 8, ny // 8)
+    ctx.set_camera(cam_s)
+    ctx.render_begin(nx // 8, ny // 8, 4, 30, capi.ALG_MIS, 1234)
+    finish = ctx.capture_rays(1 << 19)
+    ctx.render_pass(0, 4)
+    ctx.render_sync()
+    rays = finish().copy()
+    assert len(rays) >= 100_000
+    assert _check_against_oracle(ctx, mesh, rays) > 0.5
+    ctx.close()
+
+
+def test_large_obj_project_4k(tmp_path):
+    """A multi-object OBJ project of modelled-scene size (about 380 k polygons: planar quads and triangles, 31 objects, 12 light polygons, all five
+    BSDF node types; procedural, written to disk) loaded through Renderer.Load + LoadMaterials and rendered at 3840x2160 with 30 bands"""
+    from ray_tracer_amd import scene_io
+    from ray_tracer_amd.renderer import Renderer, MIS
+    paths = synth.atrium(str(tmp_path / "hall"))
+    assert paths["polygons"] >= 250_000 and paths["objects"] >= 20
+    r = Renderer(0, seed=5)
+    r.Load(paths["obj"])
+    mats, omm = scene_io.load_materials(paths["materials"]), scene_io.load_objmatmap(paths["objmatmap"])
+    assert r.LoadMaterials({name: mats[omm[name]] for name in omm})
+    st = r.ctx.stats()
+    assert st["n_faces"] == paths["polygons"] and st["n_objects"] == paths["objects"] and st["n_lights"] == 12
+    assert st["n_triangles"] > st["n_faces"]  # quads became two fan triangles each
+    nx, ny = 3840, 2160
+    r.cam.film_height = 0.024
+    r.cam.film_width = 0.024 * nx / ny
+    r.cam.aperture = 0.05
+    r.cam.SetLens(60.0, 0.4)
+    r.cam.set_Camera([0.0, 1.3, 7.5], [0.0, 1.1, 0.0], [0, 1, 0])
+    r.algorithm_type = MIS
+    r.preview_img_flag = False
+    r.samples_per_pass = 2
+    r.RenderImage(nx, ny, 2, 30)
+    film = r.spectrum_img
+    assert film.shape == (nx * ny, 30) and np.isfinite(film).all() and film.min() >= 0.0
+    lit = film.sum(1) > 0
+    assert lit.mean() > 0.8  # the camera stands inside the hall: nearly every pixel sees a lit surface
+    assert r.preview_img.shape == (nx * ny, 3) and 0.0 <= r.preview_img.min() and r.preview_img.max() <= 1.0
+    # the same film with nothing dropped, at a size where two renders are cheap; then ids and t on this scene's render rays
+    ctx = r.ctx
+    film_s, _ = _film_with_and_without_culling(ctx, 480, 270, 4, 11)
+    ratio = (film_s.sum() / (480 * 270)) / (film.sum() / (nx * ny))
+    assert 0.8 < ratio < 1.25  # same scene and camera at two resolutions: the same mean radiance, up to noise
+    ctx.render_begin(480, 270, 2, 30, capi.ALG_MIS, 1234)
+    finish = ctx.capture_rays(1 << 19)
+    ctx.render_pass(0, 2)
+    ctx.render_sync()
+    rays = finish().copy()
+    assert len(rays) >= 100_000
+    assert _check_against_oracle(ctx, r.mesh, rays) > 0.9
+    # the tree built on the device answers the same
+    hits_host, t_host = ctx.trace_closest(rays, want_t64=True)
+    ctx.set_builder(capi.BUILDER_DEVICE_LBVH)
+    ctx.upload_mesh(r.mesh)
+    hits_dev, t_dev = ctx.trace_closest(rays, want_t64=True)
+    assert np.array_equal(t_host, t_dev) and (hits_host["prim"] != hits_dev["prim"]).sum() <= 2
+    ctx.close()

@@ -16,18 +16,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def blob(n_lat, n_lon, centre, radius):
-    th = np.linspace(0.01, np.pi - 0.01, n_lat)
-    ph = np.linspace(0, 2 * np.pi, n_lon, endpoint=False)
-    T, P = np.meshgrid(th, ph, indexing="ij")
-    r = radius * (1 + 0.10 * np.sin(9 * T) * np.cos(7 * P) + 0.03 * np.sin(40 * T + 3 * P))
-    v = np.stack([r * np.sin(T) * np.cos(P), r * np.cos(T), r * np.sin(T) * np.sin(P)], -1).reshape(-1, 3) + np.asarray(centre)
-    idx = np.arange(n_lat * n_lon).reshape(n_lat, n_lon)
-    a, b = idx[:-1, :], idx[1:, :]
-    a2, b2 = np.roll(a, -1, axis=1), np.roll(b, -1, axis=1)
-    return v, np.concatenate([np.stack([a, b, b2], -1).reshape(-1, 3), np.stack([a, b2, a2], -1).reshape(-1, 3)])
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--material", default="glass")
@@ -41,7 +29,8 @@ def main():
     import bench
 
     path = "/tmp/blob_%d.ply" % args.grid
-    v, faces = blob(args.grid, args.grid, (0.0, -0.45, 0.0), 0.4)
+    from ray_tracer_amd import synth
+    v, faces = synth.blob(args.grid, args.grid, (0.0, -0.45, 0.0), 0.4)
     scene_io.write_ply(path, v, faces)
     out = {"ply_file_mb": os.path.getsize(path) / 1e6, "ply_triangles": int(len(faces))}
     t0 = time.time()
