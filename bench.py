@@ -11,12 +11,14 @@ sample indices of the same image (weak scaling: K steps per rank) into its own f
 are summed with one RCCL all-reduce inside the timed region.
 
 The JSON line also carries
-  roofline      for the dominant kernel (closest-hit traversal): algorithmic bytes, i.e.
-                rays * (32 + 16 + 64*nodes_per_ray + 48*tris_per_ray), over the kernel's device time
-                measured with HIP events on its stream inside the timed region, against 8 TB/s;
-  cpu_baseline  the fp64 CPU restatement of the reference renderer (oracle/) timed on this host's
-                cores on a bounded sample of the same workload;
-  aux           the incoherent closest-hit rate on a 1M-triangle random soup with its own roofline figures.
+  roofline      for the dominant kernel (closest-hit traversal): `achieved` = bytes that crossed the memory side of the L2 per launch
+                (rocprofv3 PMC passes over this same command, committed under profiles/) over the kernel's average duration measured
+                here with HIP events on its stream inside the timed region, against 8 TB/s; `algorithmic` prices the same launches by
+                work units counted on the CPU (nodes fetched and triangle records tested in the 8-wide tree the kernel walks, and the
+                binary-tree formula 32 + 16 + 64 * nodes + 48 * triangles next to it); `limiter` says what actually bounds the kernel;
+  cpu_baseline  the fp64 CPU restatement of the reference renderer (oracle/) timed on this host's cores on a bounded sample of the
+                same workload;
+  aux           the incoherent closest-hit rate on the 1M- and 10M-triangle random soups, each with its own traffic figures.
 """
 import argparse
 import ctypes
@@ -43,6 +45,23 @@ def recorded_traffic(pattern, kernel):
     rec = json.load(open(files[-1]))
     k = rec["kernels"].get(kernel)
     return (k, os.path.relpath(files[-1], ROOT)) if k else (None, None)
+
+
+def recorded_counters(pattern, kernel):
+    """what the committed PMC summary says about `kernel` besides traffic: lane utilisation of its vector instructions, the share
+    of wave time spent issuing them, and the share spent waiting (tools/traffic_from_profile.py); None when there is none"""
+    k, f = recorded_traffic(pattern, kernel)
+    if not k or "valu_lane_utilization" not in k:
+        return None
+    return {"valu_busy": k.get("valu_busy"), "valu_lane_utilization": k["valu_lane_utilization"],
+            "valu_issue_share_of_wave_time": k["valu_issue_share_of_wave_time"], "wait_share_of_wave_time": k["wait_share_of_wave_time"],
+            "l2_hit_rate": k.get("l2_hit_rate"), "source": f}
+
+
+def b_ray_wide(nodes_per_ray, tris_per_ray, tri_record_bytes):
+    """algorithmic bytes per closest-hit ray in the tree the kernel walks: ray in (32) + hit out (16) + one 128-byte node per node
+    fetched + one triangle record (128 bytes, or 112 in the packed layout of small scenes) per triangle tested"""
+    return 32.0 + 16.0 + 128.0 * nodes_per_ray + tri_record_bytes * tris_per_ray
 
 
 def b_ray(nodes_per_ray, tris_per_ray):
@@ -76,6 +95,11 @@ def cpu_leg(args, ctx, capi, scenes, log):
     out["cornell_nodes_per_ray"] = nv / len(rays)
     out["cornell_tris_per_ray"] = nt / len(rays)
     out["cornell_rays_sampled"] = int(len(rays))
+    wnodes, wtri = ctx.wide_bvh()
+    _, _, wt, wnv, wnt = sc.trace_wide(wnodes, wtri, rays, nthreads=threads)
+    out["cornell_wide_nodes_per_ray"] = wnv / len(rays)
+    out["cornell_wide_tris_per_ray"] = wnt / len(rays)
+    out["cornell_wide_t_mismatch"] = int((wt != t).sum())
     # GPU results on those rays must be the oracle's (a bench that measures wrong answers is worthless)
     hits, t64 = ctx.trace_closest(rays, want_t64=True)
     gp = hits["prim"].astype(np.int64)
@@ -109,14 +133,13 @@ def cpu_leg(args, ctx, capi, scenes, log):
     return out, oracle
 
 
-def soup_leg(args, ctx, capi, synth, oracle, torch, rank, log):
-    """incoherent closest hit on a random soup: Mrays/s, work units per ray, fraction of the HBM roofline"""
-    n, sigma, m = args.soup_tris, args.soup_sigma, args.soup_rays
+def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=5, host_buffer=False):
+    """incoherent closest hit on a random soup: Mrays/s, work units per ray, memory-side traffic from the committed PMC summary"""
     t0 = time.time()
     mesh = synth.soup(n, sigma, seed=12345)
     ctx.upload_mesh(mesh)
     st = ctx.stats()
-    log("soup: %d triangles uploaded in %.1f s (host BVH build %.2f s, depth %d)" % (n, time.time() - t0, st["bvh_build_seconds"], st["bvh_depth"]))
+    log("soup %s: %d triangles uploaded in %.1f s (BVH build %.2f s, depth %d)" % (tag, n, time.time() - t0, st["bvh_build_seconds"], st["bvh_depth"]))
     rays = synth.incoherent_rays(m, seed=777, start=rank * m)
     d_rays = torch.from_numpy(rays).cuda()
     d_hits = torch.empty((m, 4), dtype=torch.int32, device="cuda")
@@ -124,7 +147,6 @@ def soup_leg(args, ctx, capi, synth, oracle, torch, rank, log):
         ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr())
     ctx.render_sync()
     ctx.profile_start()
-    reps = 5
     for _ in range(reps):
         ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr())
     ctx.render_sync()
@@ -132,24 +154,31 @@ def soup_leg(args, ctx, capi, synth, oracle, torch, rank, log):
     res = {"triangles": n, "sigma": sigma, "rays_per_launch": m, "launches": reps,
            "kernel_ms_per_launch": prof["ms"] / reps, "mrays_per_s": m * reps / (prof["ms"] * 1e-3) / 1e6,
            "hit_rate": float((d_hits[:, 1] != -1).float().mean().item()), "bvh_build_s": st["bvh_build_seconds"],
-           "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"]}
-    # the host-buffer entry point (rt_trace_closest: rays and hits cross PCIe), for the record only
-    t0 = time.perf_counter()
-    ctx.trace_closest(rays)
-    res["host_buffer_mrays_per_s"] = m / (time.perf_counter() - t0) / 1e6
+           "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"], "device_mb": st["device_bytes"] / 1e6}
+    if host_buffer:
+        # the host-buffer entry point (rt_trace_closest: rays and hits cross PCIe), for the record only
+        t0 = time.perf_counter()
+        ctx.trace_closest(rays)
+        res["host_buffer_mrays_per_s"] = m / (time.perf_counter() - t0) / 1e6
     if oracle is not None:
+        # work units per ray and parity on a sample: the oracle walks the very tree the kernel walked
         sc = oracle.Scene(mesh)
-        nodes, tri_index = ctx.bvh2()
         sub = rays[:1 << 16]
-        poly, tri, t, nv, nt = sc.trace_bvh2(nodes, tri_index, sub)
+        wnodes, wtri = ctx.wide_bvh()
+        poly, tri, t, nv, nt = sc.trace_wide(wnodes, wtri, sub)
         h = d_hits[:len(sub)].cpu().numpy()
-        res["nodes_per_ray"], res["tris_per_ray"] = nv / len(sub), nt / len(sub)
-        res["b_ray"] = b_ray(res["nodes_per_ray"], res["tris_per_ray"])
-        res["achieved_gbs"] = res["mrays_per_s"] * 1e6 * res["b_ray"] / 1e9
-        res["frac_hbm"] = res["achieved_gbs"] * 1e9 / HBM_PEAK
+        res["parity_rays"] = int(len(sub))
         res["parity_prim_mismatch"] = int((h[:, 1] != poly).sum())
-    tr, tr_file = recorded_traffic("r*_soup1m_traffic.json", "k_trace<true, false>")
-    if tr is not None and n == 1000000 and m == 1 << 24:
+        res["parity_t_mismatch"] = int((h[:, 0].view(np.float32) != t.astype(np.float32)).sum())
+        res["wide_nodes_per_ray"], res["wide_tris_per_ray"] = nv / len(sub), nt / len(sub)
+        res["algorithmic_bytes_per_ray"] = b_ray_wide(res["wide_nodes_per_ray"], res["wide_tris_per_ray"], 128.0)
+        res["algorithmic_rate_gbs"] = res["mrays_per_s"] * 1e6 * res["algorithmic_bytes_per_ray"] / 1e9
+        res["algorithmic_note"] = ("48 B + 128 B per node fetched + 128 B per triangle record tested, counted by the oracle's walk of the kernel's own tree; "
+                                   "part of it is served by the L2, so this rate can exceed what HBM delivers: the traffic figures below are the measured ones")
+    tr, tr_file = recorded_traffic("r*_%s_traffic.json" % tag, "k_trace<false, false>")
+    if tr is None:
+        tr, tr_file = recorded_traffic("r*_%s_traffic.json" % tag, "k_trace<true, false>")
+    if tr is not None and tr.get("rays_per_launch", m) == m:
         # what bounds this kernel: the rate at which the memory side of the L2 serves random 128-byte lines
         # (tools/calib/random_lines.hip: 53 G lines/s from HBM, 57 G lines/s from the Infinity Cache)
         res["traffic_bytes_per_launch"] = tr["bytes_per_launch"]
@@ -175,6 +204,7 @@ def main():
     ap.add_argument("--soup-rays", type=int, default=1 << 24)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (roofline then lacks the work-unit counts)")
     ap.add_argument("--no-soup", action="store_true")
+    ap.add_argument("--no-soup10m", action="store_true", help="skip the 10M-triangle soup (about 30 s of set-up)")
     ap.add_argument("--algorithm", default="mis", choices=["naive", "nee", "mis", "bdpt"],
                     help="integrator of the timed workload (the headline metric is quoted on mis)")
     args = ap.parse_args()
@@ -272,46 +302,60 @@ def main():
     film_mean = float(film.sum().item()) / (nx * ny) * (ns_total / (per_rank * world))
     ok = bool(torch.isfinite(film).all().item())
 
-    soup = None
+    soup = soup10 = None
     if not args.no_soup:
-        soup = soup_leg(args, ctx, capi, synth, oracle, torch, rank, log)
+        soup = soup_leg(args.soup_tris, args.soup_sigma, args.soup_rays, "soup1m", ctx, capi, synth, oracle, torch, rank, log, host_buffer=True)
+        if not args.no_soup10m:
+            soup10 = soup_leg(10_000_000, 0.002, args.soup_rays, "soup10m", ctx, capi, synth, oracle, torch, rank, log, reps=3)
 
     if rank == 0:
         k = prof["closest"]
+        avg_ms = k["ms"] / max(k["launches"], 1)
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "k_trace (closest hit)", "kernel_ms_avg": k["ms"] / max(k["launches"], 1), "launches": k["launches"],
+                "kernel": "k_trace (closest hit)", "kernel_ms_avg": avg_ms, "launches": k["launches"],
                 "rays": k["items"], "kernel_ms_total": k["ms"], "mrays_per_s_in_kernel": k["items"] / max(k["ms"], 1e-9) / 1e3}
-        tr, tr_file = recorded_traffic("r*_bench_traffic.json", "k_trace<true, false>")
         default_workload = (nx, ny, spp, args.algorithm) == (1920, 1080, 16, "mis")
+        tr, tr_file = recorded_traffic("r*_bench_traffic.json", "k_trace<true, false>")
         if tr is not None and default_workload:
             roof["traffic"] = tr["bytes_per_launch"]
-            roof["traffic_note"] = ("bytes per launch on the memory side of the L2 (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes "
-                                    "over this command, recorded in %s); far below the algorithmic bytes because the small tree stays "
-                                    "in cache: only rays and hits reach HBM" % tr_file)
+            roof["achieved"] = tr["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+            roof["frac"] = roof["achieved"] * 1e9 / HBM_PEAK
+            roof["traffic_note"] = ("bytes per launch on the memory side of the L2 (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes over "
+                                    "this command, recorded in %s) over the launch duration measured in this run: the tree and the triangles of "
+                                    "this scene stay in the caches, only rays and hits reach HBM" % tr_file)
+            lim = recorded_counters("r*_bench_traffic.json", "k_trace<true, false>")
+            if lim is not None:
+                roof["limiter"] = dict(lim, what="vector instruction issue, not memory (the scene is cache resident): valu_busy is the share of SIMD time spent "
+                                                  "issuing vector instructions, valu_lane_utilization the share of their lanes that did work")
         counts = None
         if cpu is not None:
-            counts = (cpu["cornell_nodes_per_ray"], cpu["cornell_tris_per_ray"], "counted in this run")
+            counts = dict(cpu, source="counted in this run")
         elif default_workload:
             # no CPU leg (N > 1 or --no-cpu): the work-unit counts of the same scene, camera and integrator from the committed N = 1 run
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
             if files:
-                prev = json.load(open(files[-1])).get("roofline", {})
-                if prev.get("nodes_per_ray") is not None:
-                    counts = (prev["nodes_per_ray"], prev["tris_per_ray"], "from " + os.path.relpath(files[-1], ROOT))
+                prev = json.load(open(files[-1])).get("roofline", {}).get("algorithmic")
+                if prev:
+                    counts = {"cornell_nodes_per_ray": prev["bvh2_survey_formula"]["nodes_per_ray"], "cornell_tris_per_ray": prev["bvh2_survey_formula"]["tris_per_ray"],
+                              "cornell_wide_nodes_per_ray": prev["bvh8"]["nodes_per_ray"], "cornell_wide_tris_per_ray": prev["bvh8"]["tris_per_ray"],
+                              "source": "from " + os.path.relpath(files[-1], ROOT)}
         if counts is not None:
-            cpu_counts = {"cornell_nodes_per_ray": counts[0], "cornell_tris_per_ray": counts[1]}
-            roof["work_unit_counts"] = counts[2]
-            bytes_per_ray = b_ray(cpu_counts["cornell_nodes_per_ray"], cpu_counts["cornell_tris_per_ray"])
-            roof["achieved"] = k["items"] * bytes_per_ray / (k["ms"] * 1e-3) / 1e9
-            roof["frac"] = roof["achieved"] * 1e9 / HBM_PEAK
-            roof["bytes_per_ray"] = bytes_per_ray
-            roof["algorithmic_bytes_per_launch"] = k["items"] / max(k["launches"], 1) * bytes_per_ray
-            roof["nodes_per_ray"], roof["tris_per_ray"] = cpu_counts["cornell_nodes_per_ray"], cpu_counts["cornell_tris_per_ray"]
-            roof["frac_note"] = ("the algorithmic bytes price every interior-node visit of a binary tree walk at 64 B; the 8-wide tree is cache resident "
-                                 "on this scene, so the fraction can exceed 1 and says little: the kernel is bound by VALU issue here (fp64 triangle "
-                                 "tests at half rate, ~1400 vector instructions per 64 rays) and by the random-line rate of the memory system on the "
-                                 "soup under aux (frac_of_random_line_rate)")
+            rays_per_launch = k["items"] / max(k["launches"], 1)
+            def priced(nodes, tris, bytes_per_ray, note):
+                return {"nodes_per_ray": nodes, "tris_per_ray": tris, "bytes_per_ray": bytes_per_ray, "bytes_per_launch": rays_per_launch * bytes_per_ray,
+                        "rate_gbs": k["items"] * bytes_per_ray / (k["ms"] * 1e-3) / 1e9, "note": note}
+            roof["algorithmic"] = {
+                "work_unit_counts": counts["source"],
+                "bvh8": priced(counts["cornell_wide_nodes_per_ray"], counts["cornell_wide_tris_per_ray"],
+                               b_ray_wide(counts["cornell_wide_nodes_per_ray"], counts["cornell_wide_tris_per_ray"], 112.0),
+                               "48 B + 128 B per node fetched + 112 B per triangle record tested in the 8-wide tree the kernel walks (oracle's walk of that tree "
+                               "on a sample of the rendered rays); served by L1/L2 on this scene, so this is cache bandwidth, not HBM traffic"),
+                "bvh2_survey_formula": priced(counts["cornell_nodes_per_ray"], counts["cornell_tris_per_ray"],
+                                              b_ray(counts["cornell_nodes_per_ray"], counts["cornell_tris_per_ray"]),
+                                              "32 + 16 + 64 B per interior-node visit + 48 B per triangle test of an ordered, pruned binary-tree walk: the planning "
+                                              "formula; the kernel walks no binary tree, kept for comparison only"),
+            }
         line = {
             "metric": "spp/s at 1080p (Cornell box, NEE+MIS wavefront integrator); the incoherent closest-hit Mrays/s half of the metric is under aux",
             "value": args.steps * spp * world / dt, "unit": "spp/s", "n_gpus": ranks_in, "steps": args.steps, "warmup": args.warmup,
@@ -328,9 +372,9 @@ def main():
             "film_mean_per_pixel": film_mean, "film_finite": ok,
             "roofline": roof,
             "cpu_baseline": cpu["cpu"] if cpu is not None else None,
-            "aux": {"closest_hit_soup": soup, "parity_on_bench_rays": None if cpu is None else {
+            "aux": {"closest_hit_soup": soup, "closest_hit_soup_10m": soup10, "parity_on_bench_rays": None if cpu is None else {
                 "prim_mismatch": cpu["cornell_parity_prim_mismatch"], "t_mismatch": cpu["cornell_parity_t_mismatch"],
-                "rays": cpu["cornell_rays_sampled"]}},
+                "wide_walk_t_mismatch": cpu["cornell_wide_t_mismatch"], "rays": cpu["cornell_rays_sampled"]}},
         }
         print(json.dumps(line), flush=True)
     ctx.close()

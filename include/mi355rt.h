@@ -256,6 +256,23 @@ int rt_get_stats(rt_context *ctx, rt_stats *out);
 /* copies the host-built BVH2: nodes (n_nodes records) and tri_index (leaf order -> fan triangle).
  * Pass NULL pointers to query the counts only. */
 int rt_get_bvh2(rt_context *ctx, rt_bvh2_node *nodes, uint64_t *n_nodes, uint32_t *tri_index, uint64_t *n_tris);
+/* One node of the 8-wide tree the traversal kernels walk, as it lies in HBM (128 bytes = one cache line; the structure that
+ * replaces the reference's BVHNode objects, bvh.h:15-34).  Child i occupies [org + qlo[a][i] * cell_a, org + qhi[a][i] * cell_a] on
+ * axis a with cell_a = 2^(e[a] - 127); an empty slot has qlo 255 > qhi 0.  Bit i of imask: child i is an interior node, and the
+ * interior children are the nodes child_base, child_base + 1, ... in slot order.  A leaf child i holds meta[i] >> 5 triangles
+ * starting at leaf position tri_base + (meta[i] & 31).  Children sit in the slot whose three bits say on which side of the node's
+ * centre they lie. */
+typedef struct rt_wide_node {
+	float org[3];
+	uint8_t e[3], imask;
+	uint32_t child_base, tri_base;
+	uint8_t meta[8];
+	uint8_t qlo[3][8], qhi[3][8];
+	uint8_t pad[48];
+} rt_wide_node;
+/* copies the wide tree (n_nodes records, node 0 = root) and its leaf order (leaf position -> fan triangle), whichever builder made
+ * it.  Pass NULL pointers to query the counts only.  For work counting and tests. */
+int rt_get_wide_bvh(rt_context *ctx, rt_wide_node *nodes, uint64_t *n_nodes, uint32_t *tri_index, uint64_t *n_tris);
 /* replaces: BiliteralFilter::FilterImage (filter.cpp:13-51; window / sigma_d / sigma_r are the public fields of filter.h:17-27).
  * rgba, out: width * height * 4 doubles, row major, as Filter::orig_img / Filter::result.  Host buffers. */
 int rt_filter_bilateral(rt_context *ctx, const double *rgba, int width, int height, int window, double sigma_d, double sigma_r, double *out);

@@ -964,6 +964,103 @@ uint64_t orc_trace_bvh2(const orc_scene *s, const void *nodes_v, uint64_t n_node
 	return hits;
 }
 
+/* The same over the product's 8-wide tree (128-byte nodes, layout in include/mi355rt.h: rt_wide_node): child boxes are
+ * dequantised exactly in double, children are visited front to back by entry distance, boxes beyond the closest hit so far
+ * are skipped.  Counts the nodes fetched and the triangle records tested: the work the traversal kernel's memory traffic is
+ * priced with.  The triangle test is hit_triangle (object.cpp:238-284) as everywhere in this file. */
+typedef struct {
+	float org[3];
+	uint8_t e[3], imask;
+	uint32_t child_base, tri_base;
+	uint8_t meta[8];
+	uint8_t qlo[3][8], qhi[3][8];
+	uint8_t pad[48];
+} wide_node;
+
+uint64_t orc_trace_wide(const orc_scene *s, const void *nodes_v, uint64_t n_nodes, const uint32_t *tri_index,
+                        const float *rays, uint64_t n, int32_t *out_poly, int32_t *out_tri, double *out_t,
+                        uint64_t *node_visits, uint64_t *tri_tests, int nthreads)
+{
+	const wide_node *nodes = (const wide_node *)nodes_v;
+	uint64_t hits = 0, nv = 0, ntt = 0;
+	(void)n_nodes;
+	set_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : hits, nv, ntt)
+	for (int64_t i = 0; i < (int64_t)n; i++) {
+		const float *r = rays + 8 * i;
+		v3 o = V(r[0], r[1], r[2]), d = V(r[4], r[5], r[6]);
+		v3 inv = V(1.0 / d.e[0], 1.0 / d.e[1], 1.0 / d.e[2]);
+		double t_min = r[3], t_best = isinf(r[7]) ? DBL_MAX : (double)r[7];
+		int64_t best_tri = -1;
+		hitrec best;
+		struct { uint32_t node; double tn; } stack[8 * 96];
+		int sp = 0;
+		stack[sp].node = 0; stack[sp].tn = -DBL_MAX; sp++;
+		while (sp > 0) {
+			sp--;
+			if (stack[sp].tn > t_best) continue; /* found something closer since this node was pushed */
+			const wide_node *nd = &nodes[stack[sp].node];
+			nv++;
+			double cell[3];
+			for (int a = 0; a < 3; a++) cell[a] = ldexp(1.0, (int)nd->e[a] - 127);
+			struct { double tn; int slot; } order[8];
+			int nh = 0;
+			for (int c = 0; c < 8; c++) {
+				if (nd->qlo[0][c] > nd->qhi[0][c]) continue; /* empty slot */
+				float lo[3], hi[3]; /* exact: org + q * 2^k with q < 256 fits a double; slab() takes floats rounded outward */
+				double tn;
+				for (int a = 0; a < 3; a++) {
+					double l = (double)nd->org[a] + nd->qlo[a][c] * cell[a], h = (double)nd->org[a] + nd->qhi[a][c] * cell[a];
+					lo[a] = (float)l; if ((double)lo[a] > l) lo[a] = nextafterf(lo[a], -INFINITY);
+					hi[a] = (float)h; if ((double)hi[a] < h) hi[a] = nextafterf(hi[a], INFINITY);
+				}
+				if (!slab(lo, hi, o, inv, t_min, t_best, &tn)) continue;
+				int k = nh++;
+				while (k > 0 && order[k - 1].tn > tn) { order[k] = order[k - 1]; k--; }
+				order[k].tn = tn; order[k].slot = c;
+			}
+			/* leaf children first (their triangles may shorten the ray before anything is pushed), nearest first */
+			for (int k = 0; k < nh; k++) {
+				int c = order[k].slot;
+				if ((nd->imask >> c) & 1) continue;
+				if (order[k].tn > t_best) continue;
+				uint32_t first = nd->tri_base + (nd->meta[c] & 31u), count = nd->meta[c] >> 5;
+				for (uint32_t q = 0; q < count; q++) {
+					uint64_t t = tri_index[first + q];
+					uint64_t f = s->tri_poly[t];
+					uint64_t b = s->poly_begin[f], fi = t - s->tri_begin[f] + 1;
+					hitrec rec;
+					ntt++;
+					if (hit_triangle(o, d, t_min, t_best, s->pv[b], s->pv[b + fi], s->pv[b + fi + 1], s->pn[b],
+					                 s->pn[b + fi], s->pn[b + fi + 1], s->pvt[b], s->pvt[b + fi], s->pvt[b + fi + 1], s->face_normal[f], &rec)) {
+						if (best_tri < 0 || rec.t < t_best || (int64_t)t < best_tri) { /* tie -> lowest fan triangle */
+							best = rec;
+							best.poly = (int64_t)f;
+							best_tri = (int64_t)t;
+							t_best = rec.t;
+						}
+					}
+				}
+			}
+			for (int k = nh - 1; k >= 0; k--) { /* farthest first onto the stack: the nearest is popped next */
+				int c = order[k].slot;
+				if (!((nd->imask >> c) & 1)) continue;
+				uint32_t rel = 0;
+				for (int j = 0; j < c; j++) rel += (nd->imask >> j) & 1;
+				stack[sp].node = nd->child_base + rel; stack[sp].tn = order[k].tn; sp++;
+			}
+		}
+		int h = best_tri >= 0;
+		if (out_poly) out_poly[i] = h ? (int32_t)best.poly : -1;
+		if (out_tri) out_tri[i] = h ? (int32_t)best_tri : -1;
+		if (out_t) out_t[i] = h ? best.t : INFINITY;
+		hits += h;
+	}
+	if (node_visits) *node_visits = nv;
+	if (tri_tests) *tri_tests = ntt;
+	return hits;
+}
+
 /* ======================================================================================= */
 /* Materials (materialnode.cpp) and Renderer::LoadMaterials (renderer.cpp:24-44)            */
 /* ======================================================================================= */

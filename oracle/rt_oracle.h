@@ -120,6 +120,12 @@ uint64_t orc_trace_bvh2(const orc_scene *s, const void *nodes, uint64_t n_nodes,
                         const float *rays, uint64_t n, int32_t *out_poly, int32_t *out_tri, double *out_t,
                         uint64_t *node_visits, uint64_t *tri_tests, int nthreads);
 
+/* The same walk over the product's 8-wide tree (128-byte nodes: rt_wide_node of include/mi355rt.h; from rt_get_wide_bvh):
+ * counts the nodes fetched and the triangle records tested per ray, which is what the traversal kernel's traffic is priced with. */
+uint64_t orc_trace_wide(const orc_scene *s, const void *nodes, uint64_t n_nodes, const uint32_t *tri_index,
+                        const float *rays, uint64_t n, int32_t *out_poly, int32_t *out_tri, double *out_t,
+                        uint64_t *node_visits, uint64_t *tri_tests, int nthreads);
+
 /* ---------------- materials (flat table, one record per object) ---------------- */
 enum { ORC_MAT_NONE = 0, ORC_MAT_LAMBERTIAN = 1, ORC_MAT_DIFFUSE_LIGHT = 2, ORC_MAT_DIELECTRIC = 3,
        ORC_MAT_CONDUCTOR = 4, ORC_MAT_COLORED_METAL = 5 };

@@ -20,7 +20,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_environment", "rt_upload_materials", "rt_upload_material_graphs", "rt_set_camera", "rt_clear",
     "rt_trace_closest", "rt_trace_closest_static", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
     "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
-    "rt_get_stats", "rt_get_bvh2", "rt_filter_bilateral", "rt_filter_bilateral_device", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
+    "rt_get_stats", "rt_get_bvh2", "rt_get_wide_bvh", "rt_filter_bilateral", "rt_filter_bilateral_device", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
 ]
 
 RAY_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("oz", "f4"), ("tmin", "f4"),
@@ -28,7 +28,9 @@ RAY_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("oz", "f4"), ("tmin", "f4"),
 HIT_DTYPE = np.dtype([("t", "f4"), ("prim", "u4"), ("tri", "u4"), ("object", "u4")])
 BVH2_NODE_DTYPE = np.dtype([("lo0", "f4", 3), ("hi0", "f4", 3), ("lo1", "f4", 3), ("hi1", "f4", 3),
                             ("child0", "i4"), ("child1", "i4"), ("pad", "u4", 2)])
-assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 16 and BVH2_NODE_DTYPE.itemsize == 64
+WIDE_NODE_DTYPE = np.dtype([("org", "f4", 3), ("e", "u1", 3), ("imask", "u1"), ("child_base", "u4"), ("tri_base", "u4"), ("meta", "u1", 8),
+                            ("qlo", "u1", (3, 8)), ("qhi", "u1", (3, 8)), ("pad", "u1", 48)])
+assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 16 and BVH2_NODE_DTYPE.itemsize == 64 and WIDE_NODE_DTYPE.itemsize == 128
 
 
 class Mesh(C.Structure):
@@ -121,6 +123,7 @@ def load():
     lib.rt_film_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.rt_get_bvh2.argtypes = [vp, vp, C.POINTER(u64), vp, C.POINTER(u64)]
+    lib.rt_get_wide_bvh.argtypes = [vp, vp, C.POINTER(u64), vp, C.POINTER(u64)]
     lib.rt_stream.argtypes = [vp]
     lib.rt_stream.restype = vp
     lib.rt_profile_start.argtypes = [vp]
@@ -308,6 +311,15 @@ class Context:
         nodes = np.zeros(nn.value, dtype=BVH2_NODE_DTYPE)
         tri_index = np.zeros(nt.value, dtype=np.uint32)
         self._check(self.lib.rt_get_bvh2(self.h, _ptr(nodes), C.byref(nn), _ptr(tri_index), C.byref(nt)))
+        return nodes, tri_index
+
+    def wide_bvh(self):
+        """the 8-wide tree the kernels walk: (nodes as WIDE_NODE_DTYPE records, leaf position -> fan triangle)"""
+        nn, nt = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.rt_get_wide_bvh(self.h, None, C.byref(nn), None, C.byref(nt)))
+        nodes = np.zeros(nn.value, dtype=WIDE_NODE_DTYPE)
+        tri_index = np.zeros(nt.value, dtype=np.uint32)
+        self._check(self.lib.rt_get_wide_bvh(self.h, _ptr(nodes), C.byref(nn), _ptr(tri_index), C.byref(nt)))
         return nodes, tri_index
 
     def stream(self):

@@ -558,6 +558,21 @@ int rt_get_bvh2(rt_context *ctx, rt_bvh2_node *nodes, uint64_t *n_nodes, uint32_
 	return RT_OK;
 }
 
+int rt_get_wide_bvh(rt_context *ctx, rt_wide_node *nodes, uint64_t *n_nodes, uint32_t *tri_index, uint64_t *n_tris)
+{
+	static_assert(sizeof(rt_wide_node) == sizeof(WideNode), "the public record is the device record");
+	if (!ctx) return RT_ERR_INVALID;
+	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_get_wide_bvh: no mesh uploaded");
+	if (n_nodes) *n_nodes = ctx->device_nodes;
+	if (n_tris) *n_tris = ctx->wide.tri_index.size();
+	if (nodes) { // from HBM: the device builder leaves no host copy
+		if (!use_device(ctx)) return RT_ERR_HIP;
+		if (ctx->fail_hip(hipMemcpy(nodes, ctx->d_nodes, ctx->device_nodes * sizeof(WideNode), hipMemcpyDeviceToHost), "hipMemcpy(wide nodes)")) return RT_ERR_HIP;
+	}
+	if (tri_index) std::memcpy(tri_index, ctx->wide.tri_index.data(), ctx->wide.tri_index.size() * sizeof(uint32_t));
+	return RT_OK;
+}
+
 int rt_filter_bilateral_device(rt_context *ctx, const void *d_rgba, int width, int height, int window, double sigma_d, double sigma_r, void *d_out)
 {
 	if (!ctx || !d_rgba || !d_out) return set_err(ctx, RT_ERR_INVALID, "rt_filter_bilateral: NULL argument");

@@ -95,6 +95,8 @@ def lib():
         L.orc_trace_any.restype = u64
         L.orc_trace_bvh2.argtypes = [vp, vp, u64, vp, vp, u64, vp, vp, vp, C.POINTER(u64), C.POINTER(u64), C.c_int]
         L.orc_trace_bvh2.restype = u64
+        L.orc_trace_wide.argtypes = [vp, vp, u64, vp, vp, u64, vp, vp, vp, C.POINTER(u64), C.POINTER(u64), C.c_int]
+        L.orc_trace_wide.restype = u64
         L.orc_scene_set_materials.argtypes = [vp, C.POINTER(OrcMaterial), C.c_uint32]
         L.orc_scene_n_lights.argtypes = [vp]
         L.orc_scene_n_lights.restype = u64
@@ -174,6 +176,19 @@ class Scene:
         poly, tri, t = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float64)
         nv, nt = C.c_uint64(), C.c_uint64()
         lib().orc_trace_bvh2(self.h, _p(nodes), len(nodes), _p(tri_index), _p(rays), n, _p(poly), _p(tri), _p(t),
+                             C.byref(nv), C.byref(nt), nthreads)
+        return poly, tri, t, nv.value, nt.value
+
+    def trace_wide(self, nodes, tri_index, rays, nthreads=0):
+        """ordered, pruned traversal over the product's 8-wide tree; returns poly, tri, t, nodes fetched, triangle records tested"""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        nodes = np.ascontiguousarray(nodes)
+        assert nodes.dtype.itemsize == 128
+        tri_index = np.ascontiguousarray(tri_index, dtype=np.uint32)
+        n = len(rays)
+        poly, tri, t = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float64)
+        nv, nt = C.c_uint64(), C.c_uint64()
+        lib().orc_trace_wide(self.h, _p(nodes), len(nodes), _p(tri_index), _p(rays), n, _p(poly), _p(tri), _p(t),
                              C.byref(nv), C.byref(nt), nthreads)
         return poly, tri, t, nv.value, nt.value
 

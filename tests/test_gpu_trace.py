@@ -107,6 +107,30 @@ def test_soup_closest(ctx, n, sigma):
     check_closest(hits[:len(sub)], t64[:len(sub)], r_poly, r_tri, r_t)
 
 
+@pytest.mark.parametrize("builder", [capi.BUILDER_HOST_SAH, capi.BUILDER_DEVICE_LBVH])
+def test_wide_tree_export_walked_by_the_oracle(ctx, cornell_dir, builder):
+    """rt_get_wide_bvh hands out the 8-wide tree the kernels walk; the oracle's own walk over it (exact boxes, the reference's triangle
+    test) finds the hits the GPU reports, and its visit counts are the per-ray work figures of the benchmark"""
+    for mesh, rays in ((oracle.cornell_setup(cornell_dir, 8, 8)[0], None), (synth.soup(50000, 0.01, seed=3), None)):
+        ctx.set_builder(builder)
+        ctx.upload_mesh(mesh)
+        ctx.set_builder(capi.BUILDER_AUTO)
+        nodes, tri_index = ctx.wide_bvh()
+        n_tris = int(ctx.stats()["n_triangles"])
+        assert len(nodes) >= 1 and sorted(tri_index.tolist()) == list(range(n_tris))
+        # every triangle sits in exactly one leaf child
+        counts = (nodes["meta"] >> 5).astype(np.int64)
+        leaf = ((nodes["imask"][:, None] >> np.arange(8)) & 1) == 0
+        assert (counts * leaf).sum() == n_tris
+        rays = synth.incoherent_rays(60000, seed=777)
+        rays[:, 0:3] *= 0.95
+        sc = oracle.Scene(mesh)
+        hits, t64 = ctx.trace_closest(rays, want_t64=True)
+        poly, tri, t, nv, nt = sc.trace_wide(nodes, tri_index, rays)
+        check_closest(hits, t64, poly, tri, t, allow_ties=False)
+        assert 1.0 <= nv / len(rays) < 60 and nt / len(rays) < 20
+
+
 def test_soup_any_hit(ctx):
     mesh = synth.soup(100000, 0.01, seed=12345)
     sc = oracle.Scene(mesh)
