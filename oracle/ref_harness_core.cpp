@@ -1,6 +1,6 @@
 /*
  * ref_harness_core.cpp -- extern "C" wrappers around reference translation units that compile
- * unmodified in the build container: aabb.cpp, onb.cpp, spectrum.cpp and the header-only camera.h.
+ * unmodified in the build container: aabb.cpp, onb.cpp, spectrum.cpp and the header-only camera.h, vec3.h, ray.h.
  * TEST INFRASTRUCTURE ONLY: used to pin oracle/rt_oracle.c and to generate tests/golden vectors.
  * It is built only where the reference checkout exists; nothing here is reference code.
  */
@@ -15,6 +15,28 @@ static dvec3 L(const double *p) { return dvec3(p[0], p[1], p[2]); }
 static void S(double *p, const dvec3 &v) { p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; }
 
 extern "C" {
+
+/* vec3.h: dot, cross, length, squared_length, unit_vector, the component-wise and scalar operators, rodrigues (axis = unit(b)).
+ * out: dot, length(a), squared_length(a), then 3 each of cross, unit(a), a*b, a/b, t*a, a/t, a+b, a-b, -a, rodrigues = 33 doubles */
+void ref_vec3_ops(const double *a_, const double *b_, double t, double *out)
+{
+	const dvec3 a = L(a_), b = L(b_);
+	out[0] = dot(a, b);
+	out[1] = a.length();
+	out[2] = a.squared_length();
+	S(out + 3, cross(a, b));
+	S(out + 6, unit_vector(a));
+	S(out + 9, a * b);
+	S(out + 12, a / b);
+	S(out + 15, t * a);
+	S(out + 18, a / t);
+	S(out + 21, a + b);
+	S(out + 24, a - b);
+	S(out + 27, -a);
+	S(out + 30, rodrigues(a, unit_vector(b), t));
+}
+/* ray.h: ray(a, b).point_at_parameter(t) */
+void ref_ray_point(const double *o, const double *d, double t, double *out) { S(out, ray(L(o), L(d)).point_at_parameter(t)); }
 
 int ref_aabb_hit(const double *minp, const double *maxp, const double *o, const double *d, double t_min, double t_max)
 {

@@ -37,6 +37,39 @@ static inline v3 vunit(v3 a) { return vdiv(a, vlen(a)); }                       
 static inline v3 vload(const double *p) { return V(p[0], p[1], p[2]); }
 static inline void vstore(double *p, v3 a) { p[0] = a.e[0]; p[1] = a.e[1]; p[2] = a.e[2]; }
 
+/* rodrigues(v, axis, theta), vec3.h:248-256 */
+static inline v3 vrodrigues(v3 v, v3 ax, double theta)
+{
+	double c = cos(theta), sn = sin(theta);
+	double nx = ax.e[0], ny = ax.e[1], nz = ax.e[2];
+	v3 r0 = V(c + nx * nx * (1.0 - c), nx * ny * (1.0 - c) - nz * sn, nx * nz * (1.0 - c) + ny * sn);
+	v3 r1 = V(ny * nx * (1.0 - c) + nz * sn, c + ny * ny * (1.0 - c), ny * nz * (1.0 - c) - nx * sn);
+	v3 r2 = V(nz * nx * (1.0 - c) - ny * sn, nz * ny * (1.0 - c) + nx * sn, c + nz * nz * (1.0 - c));
+	return V(vdot(r0, v), vdot(r1, v), vdot(r2, v));
+}
+
+/* The vector helpers every function of this file is built from, exported so that they can be checked against vec3.h compiled
+ * unmodified: dot, length(a), squared_length(a), then cross, unit(a), a*b, a/b, t*a, a/t, a+b, a-b, -a, rodrigues(a, unit(b), t). */
+void orc_vec3_ops(const double *a_, const double *b_, double t, double *out)
+{
+	const v3 a = vload(a_), b = vload(b_);
+	out[0] = vdot(a, b);
+	out[1] = vlen(a);
+	out[2] = vlen2(a);
+	vstore(out + 3, vcross(a, b));
+	vstore(out + 6, vunit(a));
+	vstore(out + 9, V(a.e[0] * b.e[0], a.e[1] * b.e[1], a.e[2] * b.e[2])); /* vec3.h:92-96 */
+	vstore(out + 12, V(a.e[0] / b.e[0], a.e[1] / b.e[1], a.e[2] / b.e[2])); /* vec3.h:97-101 */
+	vstore(out + 15, vscale(t, a));
+	vstore(out + 18, vdiv(a, t));
+	vstore(out + 21, vadd(a, b));
+	vstore(out + 24, vsub(a, b));
+	vstore(out + 27, vneg(a));
+	vstore(out + 30, vrodrigues(a, vunit(b), t));
+}
+/* ray::point_at_parameter, ray.h:25-27 */
+void orc_ray_point(const double *o, const double *d, double t, double *out) { vstore(out, vadd(vload(o), vscale(t, vload(d)))); }
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP
@@ -343,6 +376,30 @@ double orc_power_heuristic(double pdf1, double pdf2, double beta) /* pdf.cpp:139
 	if (isinf(pdf1))
 		return 1.0;
 	return pow(pdf1, beta) / (pow(pdf1, beta) + pow(pdf2, beta));
+}
+
+/* MixturePdf (pdf.cpp:116-135; constructed nowhere in the reference, restated because the hot-path description names it).
+ * Generate(): one uniform number r picks component i = the first with r < (i+1)/l, the last one otherwise.
+ * PdfVal(): the plain average of the components' values.  Parity unpinned: pdf.cpp does not compile here (pdf.h -> object.h ->
+ * obj.h needs Boost) and the reference holds no fixture for it. */
+uint64_t orc_mixture_pick(double r, uint64_t l)
+{
+	for (uint64_t i = 0; i < l; i++)
+		if (i == (l - 1) || r < ((double)(i + 1) / (double)l))
+			return i;
+	return l - 1;
+}
+double orc_mixture_pdf(const double *component_pdf, uint64_t l)
+{
+	double sum = 0.0;
+	for (uint64_t i = 0; i < l; i++) sum += component_pdf[i];
+	return sum / (double)l;
+}
+/* CosinePdf::PdfVal (pdf.cpp:76-84): dot(direction, w) / pi (the direction is not normalised there), 0 below the horizon */
+double orc_cosine_pdf(const double *direction, const double *w)
+{
+	double cos_theta = vdot(vload(direction), vload(w));
+	return cos_theta >= 0.0 ? cos_theta / M_PI : 0.0;
 }
 
 void orc_cosine_hemisphere(double r1, double r2, double out[3]) /* pdf.cpp:36-46 (z is 1-r2 as there) */
@@ -1414,17 +1471,10 @@ static void graph_eval(const orc_scene *s, uint32_t begin, uint32_t len, v3 vt, 
 			sp--;
 			break;
 		}
-		case 16: {
-			v3 v = st[sp - 3].v, nn = vunit(st[sp - 2].v);
-			double c = cos(st[sp - 1].s[0]), sn = sin(st[sp - 1].s[0]);
-			double nx = nn.e[0], ny = nn.e[1], nz = nn.e[2];
-			v3 r0 = V(c + nx * nx * (1.0 - c), nx * ny * (1.0 - c) - nz * sn, nx * nz * (1.0 - c) + ny * sn);
-			v3 r1 = V(ny * nx * (1.0 - c) + nz * sn, c + ny * ny * (1.0 - c), ny * nz * (1.0 - c) - nx * sn);
-			v3 r2 = V(nz * nx * (1.0 - c) - ny * sn, nz * ny * (1.0 - c) + nx * sn, c + nz * nz * (1.0 - c));
-			st[sp - 3].v = V(vdot(r0, v), vdot(r1, v), vdot(r2, v));
+		case 16:
+			st[sp - 3].v = vrodrigues(st[sp - 3].v, vunit(st[sp - 2].v), st[sp - 1].s[0]);
 			sp -= 2;
 			break;
-		}
 		case 17: st[sp].is_vec = 0; memset(st[sp].s, 0, sizeof(st[sp].s)); st[sp].s[0] = s->g_scalars[arg]; sp++; break;
 		default: break;
 		}

@@ -54,6 +54,11 @@ double orc_rfresnel(double cos_theta, double n);                                
 double orc_cfresnel(double cos_theta, double n_re, double n_im);                 /* material.cpp:26-34 */
 double orc_power_heuristic(double pdf1, double pdf2, double beta);               /* pdf.cpp:139-146 */
 void   orc_cosine_hemisphere(double r1, double r2, double out[3]);               /* pdf.cpp:36-46 */
+double orc_cosine_pdf(const double *direction, const double *w);                   /* pdf.cpp:76-84 */
+uint64_t orc_mixture_pick(double r, uint64_t l);                                   /* MixturePdf::Generate, pdf.cpp:116-126 */
+double orc_mixture_pdf(const double *component_pdf, uint64_t l);                   /* MixturePdf::PdfVal, pdf.cpp:128-135 */
+void   orc_vec3_ops(const double *a, const double *b, double t, double *out33);    /* vec3.h operators, dot, cross, unit_vector, rodrigues */
+void   orc_ray_point(const double *o, const double *d, double t, double *out);     /* ray.h:25-27 */
 
 /* ---------------- camera (camera.h:101-209) ---------------- */
 typedef struct orc_camera {

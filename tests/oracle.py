@@ -63,6 +63,14 @@ def lib():
         L.orc_cfresnel.restype = d
         L.orc_power_heuristic.argtypes = [d, d, d]
         L.orc_power_heuristic.restype = d
+        L.orc_cosine_pdf.argtypes = [vp, vp]
+        L.orc_cosine_pdf.restype = d
+        L.orc_mixture_pick.argtypes = [d, u64]
+        L.orc_mixture_pick.restype = u64
+        L.orc_mixture_pdf.argtypes = [vp, u64]
+        L.orc_mixture_pdf.restype = d
+        L.orc_vec3_ops.argtypes = [vp, vp, d, vp]
+        L.orc_ray_point.argtypes = [vp, vp, d, vp]
         L.orc_cosine_hemisphere.argtypes = [d, d, vp]
         L.orc_camera_default.argtypes = [C.POINTER(OrcCamera)]
         L.orc_camera_set_lens.argtypes = [C.POINTER(OrcCamera), d, d]
@@ -293,6 +301,9 @@ def ref_core():
     L.ref_rgb.argtypes = [vp, vp]
     L.ref_rgb_to_spectrum.argtypes = [vp, vp]
     L.ref_camera_get_ray.argtypes = [d, d, d, vp, d, d, vp, vp, vp, d, d, d, C.c_long, vp]
+    if hasattr(L, "ref_vec3_ops"):  # a library built before these wrappers existed lacks them
+        L.ref_vec3_ops.argtypes = [vp, vp, d, vp]
+        L.ref_ray_point.argtypes = [vp, vp, d, vp]
     return L
 
 
