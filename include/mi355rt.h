@@ -233,6 +233,32 @@ int rt_download_film(rt_context *ctx, double *spectrum_img);
 int rt_download_preview(rt_context *ctx, int samples_done, double *preview_img);
 int rt_film_device_ptr(rt_context *ctx, void **d_film, size_t *bytes);
 
+/* ---- several GPUs in one process ---- */
+/* replaces: `#pragma omp parallel for` over image columns (renderer.cpp:74-77), the reference's only parallel construct.
+ * A group is one context per entry of `devices` (an ordinal may repeat: several contexts on one GPU), each with a full copy of the
+ * scene.  A render pass is split by sample index -- member i of n renders the i-th block of the pass's samples of every pixel into
+ * its own film, on a host thread of its own -- and random streams are keyed by (pixel, sample), so the image does not depend on n.
+ * The downloads gather the member films onto the first member's GPU (peer copies over xGMI) and sum them there; nothing else is
+ * exchanged.  The scene calls forward to every member and mean what their rt_* namesakes mean; all return the first failure,
+ * whose text rt_group_last_error holds.  One host thread at a time per group. */
+typedef struct rt_group rt_group;
+int rt_group_create(const int *devices, int n, rt_group **out);
+void rt_group_destroy(rt_group *g);
+const char *rt_group_last_error(const rt_group *g);
+int rt_group_size(const rt_group *g);
+rt_context *rt_group_context(rt_group *g, int i); /* member i, for rt_get_stats, rt_set_builder, rt_profile_* */
+int rt_group_upload_mesh(rt_group *g, const rt_mesh *mesh);
+int rt_group_upload_materials(rt_group *g, const rt_material *per_object, uint32_t n_objects);
+int rt_group_upload_material_graphs(rt_group *g, const rt_material_graphs *graphs);
+int rt_group_set_environment(rt_group *g, const uint8_t *texels, int width, int height, int bpp, double brightness);
+int rt_group_set_camera(rt_group *g, const rt_camera *cam);
+int rt_group_clear(rt_group *g);
+int rt_group_render_begin(rt_group *g, int nx, int ny, int ns, int spectral_samples, int algorithm, uint64_t seed);
+int rt_group_render_pass(rt_group *g, int first_sample, int n_samples);
+int rt_group_render_sync(rt_group *g);
+int rt_group_download_film(rt_group *g, double *spectrum_img);                       /* the sum of the member films */
+int rt_group_download_preview(rt_group *g, int samples_done, double *preview_img);   /* tonemap of that sum */
+
 /* ---- introspection (tests, roofline accounting) ---- */
 /* Per-kernel device time measured with HIP events recorded on the stream each kernel is launched on.
  * items = rays for the two traversal kernels, paths / connections for the others. */

@@ -20,6 +20,9 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_environment", "rt_upload_materials", "rt_upload_material_graphs", "rt_set_camera", "rt_clear",
     "rt_trace_closest", "rt_trace_closest_static", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
     "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
+    "rt_group_create", "rt_group_destroy", "rt_group_last_error", "rt_group_size", "rt_group_context", "rt_group_upload_mesh",
+    "rt_group_upload_materials", "rt_group_upload_material_graphs", "rt_group_set_environment", "rt_group_set_camera", "rt_group_clear",
+    "rt_group_render_begin", "rt_group_render_pass", "rt_group_render_sync", "rt_group_download_film", "rt_group_download_preview",
     "rt_get_stats", "rt_get_bvh2", "rt_get_wide_bvh", "rt_filter_bilateral", "rt_filter_bilateral_device", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
 ]
 
@@ -129,6 +132,25 @@ def load():
     lib.rt_profile_start.argtypes = [vp]
     lib.rt_profile_stop.argtypes = [vp, C.POINTER(Profile)]
     lib.rt_render_capture_rays.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    lib.rt_group_create.argtypes = [C.POINTER(C.c_int), i32, C.POINTER(vp)]
+    lib.rt_group_destroy.argtypes = [vp]
+    lib.rt_group_destroy.restype = None
+    lib.rt_group_last_error.argtypes = [vp]
+    lib.rt_group_last_error.restype = C.c_char_p
+    lib.rt_group_size.argtypes = [vp]
+    lib.rt_group_context.argtypes = [vp, i32]
+    lib.rt_group_context.restype = vp
+    lib.rt_group_upload_mesh.argtypes = [vp, C.POINTER(Mesh)]
+    lib.rt_group_upload_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32]
+    lib.rt_group_upload_material_graphs.argtypes = [vp, vp]
+    lib.rt_group_set_environment.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
+    lib.rt_group_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    lib.rt_group_clear.argtypes = [vp]
+    lib.rt_group_render_begin.argtypes = [vp, i32, i32, i32, i32, i32, u64]
+    lib.rt_group_render_pass.argtypes = [vp, i32, i32]
+    lib.rt_group_render_sync.argtypes = [vp]
+    lib.rt_group_download_film.argtypes = [vp, vp]
+    lib.rt_group_download_preview.argtypes = [vp, i32, vp]
     _lib = lib
     return lib
 
@@ -346,3 +368,109 @@ class Context:
             self._check(self.lib.rt_render_capture_rays(self.h, None, 0, None))
             return buf[:n.value]
         return finish
+
+
+class _Member(Context):
+    """a context owned by a group: usable for per-member calls (stats, profile), never destroyed on its own"""
+
+    def __init__(self, lib, handle):
+        self.lib = lib
+        self.h = C.c_void_p(handle)
+        self._keep = {}
+
+    def close(self):
+        self.h = None
+
+
+class Group:
+    """One rt_group: a context per entry of `devices` (ordinals may repeat), the samples of every pass split between them, films summed
+    when they are read.  Same method names as Context for what a render needs."""
+
+    def __init__(self, devices):
+        self.lib = load()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.lib.rt_group_create(arr, len(devices), C.byref(h))
+        if rc != OK:
+            raise BackendError(rc, self.lib.rt_group_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise BackendError(rc, self.lib.rt_group_last_error(self.h).decode())
+
+    def size(self):
+        return self.lib.rt_group_size(self.h)
+
+    def member(self, i):
+        return _Member(self.lib, self.lib.rt_group_context(self.h, i))
+
+    def upload_mesh(self, mesh):
+        v = np.ascontiguousarray(mesh["v"], dtype=np.float64).reshape(-1, 3)
+        vt = np.ascontiguousarray(mesh["vt"], dtype=np.float64).reshape(-1, 3)
+        vn = np.ascontiguousarray(mesh["vn"], dtype=np.float64).reshape(-1, 3)
+        corners = np.ascontiguousarray(mesh["corners"], dtype=np.int64).reshape(-1, 3)
+        fb = np.ascontiguousarray(mesh["face_begin"], dtype=np.uint64)
+        ob = np.ascontiguousarray(mesh["object_begin"], dtype=np.uint64)
+        m = Mesh(_ptr(v), len(v), _ptr(vt), len(vt), _ptr(vn), len(vn), _ptr(corners), _ptr(fb), len(fb) - 1, _ptr(ob), len(ob) - 1)
+        self._check(self.lib.rt_group_upload_mesh(self.h, C.byref(m)))
+
+    def upload_materials(self, materials):
+        arr = (Material * max(len(materials), 1))()
+        for i, m in enumerate(materials):
+            arr[i].type = int(m["type"])
+            arr[i].light_flag = int(bool(m["light_flag"]))
+            for k in range(NBINS):
+                arr[i].a[k] = float(m["a"][k])
+                arr[i].b[k] = float(m["b"][k])
+        self._check(self.lib.rt_group_upload_materials(self.h, arr, len(materials)))
+        for i in range(self.size()):  # per-hit programs go up member by member through the one code path that builds their tables
+            self.member(i).upload_material_graphs(materials)
+
+    def set_camera(self, cam):
+        c = Camera()
+        for name in ("film_sensitivity", "aperture", "film_width", "film_height", "d", "lens_maker_coefficient"):
+            setattr(c, name, float(getattr(cam, name)))
+        for k in range(NBINS):
+            c.n[k] = float(cam.n[k])
+        for name in ("origin", "film_lower_left_corner", "horizontal", "vertical", "w"):
+            vec = getattr(cam, name)
+            for k in range(3):
+                getattr(c, name)[k] = float(vec[k])
+        self._check(self.lib.rt_group_set_camera(self.h, C.byref(c)))
+
+    def clear(self):
+        self._check(self.lib.rt_group_clear(self.h))
+
+    def render_begin(self, nx, ny, ns, spectral_samples, algorithm, seed=0):
+        self._dims = (nx, ny)
+        self._check(self.lib.rt_group_render_begin(self.h, nx, ny, ns, spectral_samples, algorithm, seed))
+
+    def render_pass(self, first_sample, n_samples):
+        self._check(self.lib.rt_group_render_pass(self.h, first_sample, n_samples))
+
+    def render_sync(self):
+        self._check(self.lib.rt_group_render_sync(self.h))
+
+    def download_film(self):
+        nx, ny = self._dims
+        out = np.zeros((nx * ny, NBINS), dtype=np.float64)
+        self._check(self.lib.rt_group_download_film(self.h, _ptr(out)))
+        return out
+
+    def download_preview(self, samples_done):
+        nx, ny = self._dims
+        out = np.zeros((nx * ny, 3), dtype=np.float64)
+        self._check(self.lib.rt_group_download_preview(self.h, samples_done, _ptr(out)))
+        return out

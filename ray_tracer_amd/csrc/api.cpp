@@ -3,7 +3,9 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 #include "context.h"
 #include "device_build.h"
@@ -604,6 +606,193 @@ int rt_filter_bilateral(rt_context *ctx, const double *rgba, int width, int heig
 }
 
 void *rt_stream(rt_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---- groups: one context per GPU (or several on one), samples of a pass split between them
+} // extern "C"
+
+struct rt_group {
+	std::vector<rt_context *> members;
+	float *d_sum = nullptr, *d_stage = nullptr; // on the first member's device: the summed film, and one member film in transit
+	size_t sum_elems = 0;
+	std::string error;
+};
+
+namespace {
+// runs f(member index) for every member on a thread of its own (a member's calls block on its GPU) and returns the first failure
+template <class F>
+int for_each_member(rt_group *g, F f)
+{
+	const size_t n = g->members.size();
+	std::vector<int> rc(n, RT_OK);
+	if (n == 1) rc[0] = f(0);
+	else {
+		std::vector<std::thread> th;
+		for (size_t i = 0; i < n; i++) th.emplace_back([&, i] { rc[i] = f(i); });
+		for (auto &t : th) t.join();
+	}
+	for (size_t i = 0; i < n; i++)
+		if (rc[i] != RT_OK) {
+			g->error = "member " + std::to_string(i) + " (device " + std::to_string(g->members[i]->device) + "): " + rt_last_error(g->members[i]);
+			return rc[i];
+		}
+	return RT_OK;
+}
+
+// the i-th of n blocks of `count` samples starting at `first` (blocks differ by at most one sample and tile the range)
+void member_samples(int i, int n, int first, int count, int &m_first, int &m_count)
+{
+	const int base = count / n, rem = count % n;
+	m_first = first + i * base + std::min(i, rem);
+	m_count = base + (i < rem ? 1 : 0);
+}
+
+int group_fail(rt_group *g, int code, const std::string &msg)
+{
+	g->error = msg;
+	return code;
+}
+
+// sums the member films into g->d_sum on the first member's device; every member must have finished (rt_render_sync)
+int group_sum_films(rt_group *g)
+{
+	rt_context *root = g->members[0];
+	if (!root->render.begun) return group_fail(g, RT_ERR_INVALID, "rt_group: nothing rendered");
+	const size_t elems = (size_t)root->render.nx * root->render.ny * RT_NBINS, bytes = elems * sizeof(float);
+	hipError_t e = hipSetDevice(root->device);
+	if (e == hipSuccess && g->sum_elems != elems) {
+		if (g->d_sum) (void)hipFree(g->d_sum);
+		if (g->d_stage) (void)hipFree(g->d_stage);
+		g->d_sum = g->d_stage = nullptr;
+		g->sum_elems = 0;
+		e = hipMalloc((void **)&g->d_sum, bytes);
+		if (e == hipSuccess && g->members.size() > 1) e = hipMalloc((void **)&g->d_stage, bytes);
+		if (e == hipSuccess) g->sum_elems = elems;
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(g->d_sum, root->render.d_film, bytes, hipMemcpyDeviceToDevice, root->stream);
+	for (size_t i = 1; i < g->members.size() && e == hipSuccess; i++) {
+		rt_context *m = g->members[i];
+		if (m->device == root->device) e = render_accumulate_film(g->d_sum, m->render.d_film, elems, root->stream);
+		else {
+			e = hipMemcpyPeerAsync(g->d_stage, root->device, m->render.d_film, m->device, bytes, root->stream);
+			if (e == hipSuccess) e = render_accumulate_film(g->d_sum, g->d_stage, elems, root->stream);
+		}
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(root->stream);
+	if (e != hipSuccess) return group_fail(g, RT_ERR_HIP, std::string("rt_group: summing the member films: ") + hipGetErrorString(e));
+	return RT_OK;
+}
+} // namespace
+
+extern "C" {
+
+int rt_group_create(const int *devices, int n, rt_group **out)
+{
+	if (!out) return set_err(nullptr, RT_ERR_INVALID, "rt_group_create: out is NULL");
+	*out = nullptr;
+	if (!devices || n <= 0 || n > 64) return set_err(nullptr, RT_ERR_INVALID, "rt_group_create: needs 1..64 device ordinals");
+	rt_group *g = new (std::nothrow) rt_group();
+	if (!g) return set_err(nullptr, RT_ERR_INVALID, "rt_group_create: out of host memory");
+	for (int i = 0; i < n; i++) {
+		rt_context *c = nullptr;
+		int rc = rt_create(devices[i], &c);
+		if (rc != RT_OK) { // rt_last_error(NULL) holds the text
+			rt_group_destroy(g);
+			return rc;
+		}
+		g->members.push_back(c);
+	}
+	*out = g;
+	return RT_OK;
+}
+
+void rt_group_destroy(rt_group *g)
+{
+	if (!g) return;
+	if (!g->members.empty()) {
+		(void)hipSetDevice(g->members[0]->device);
+		if (g->d_sum) (void)hipFree(g->d_sum);
+		if (g->d_stage) (void)hipFree(g->d_stage);
+	}
+	for (rt_context *c : g->members) rt_destroy(c);
+	delete g;
+}
+
+const char *rt_group_last_error(const rt_group *g) { return g ? g->error.c_str() : g_create_error.c_str(); }
+int rt_group_size(const rt_group *g) { return g ? (int)g->members.size() : 0; }
+rt_context *rt_group_context(rt_group *g, int i) { return (g && i >= 0 && (size_t)i < g->members.size()) ? g->members[i] : nullptr; }
+
+int rt_group_upload_mesh(rt_group *g, const rt_mesh *mesh)
+{
+	if (!g) return RT_ERR_INVALID;
+	return for_each_member(g, [&](size_t i) { return rt_upload_mesh(g->members[i], mesh); });
+}
+int rt_group_upload_materials(rt_group *g, const rt_material *per_object, uint32_t n_objects)
+{
+	if (!g) return RT_ERR_INVALID;
+	return for_each_member(g, [&](size_t i) { return rt_upload_materials(g->members[i], per_object, n_objects); });
+}
+int rt_group_upload_material_graphs(rt_group *g, const rt_material_graphs *graphs)
+{
+	if (!g) return RT_ERR_INVALID;
+	return for_each_member(g, [&](size_t i) { return rt_upload_material_graphs(g->members[i], graphs); });
+}
+int rt_group_set_environment(rt_group *g, const uint8_t *texels, int width, int height, int bpp, double brightness)
+{
+	if (!g) return RT_ERR_INVALID;
+	return for_each_member(g, [&](size_t i) { return rt_set_environment(g->members[i], texels, width, height, bpp, brightness); });
+}
+int rt_group_set_camera(rt_group *g, const rt_camera *cam)
+{
+	if (!g) return RT_ERR_INVALID;
+	return for_each_member(g, [&](size_t i) { return rt_set_camera(g->members[i], cam); });
+}
+int rt_group_clear(rt_group *g)
+{
+	if (!g) return RT_ERR_INVALID;
+	return for_each_member(g, [&](size_t i) { return rt_clear(g->members[i]); });
+}
+int rt_group_render_begin(rt_group *g, int nx, int ny, int ns, int spectral_samples, int algorithm, uint64_t seed)
+{
+	if (!g) return RT_ERR_INVALID;
+	// every member gets the whole render's ns (the film weight is 1 / ns per sample) and the same seed: streams are keyed by (pixel, sample)
+	return for_each_member(g, [&](size_t i) { return rt_render_begin(g->members[i], nx, ny, ns, spectral_samples, algorithm, seed, nullptr); });
+}
+int rt_group_render_pass(rt_group *g, int first_sample, int n_samples)
+{
+	if (!g) return RT_ERR_INVALID;
+	if (first_sample < 0 || n_samples < 0) return group_fail(g, RT_ERR_INVALID, "rt_group_render_pass: negative sample range");
+	const int n = (int)g->members.size();
+	return for_each_member(g, [&](size_t i) {
+		int f, c;
+		member_samples((int)i, n, first_sample, n_samples, f, c);
+		return rt_render_pass(g->members[i], f, c);
+	});
+}
+int rt_group_render_sync(rt_group *g)
+{
+	if (!g) return RT_ERR_INVALID;
+	return for_each_member(g, [&](size_t i) { return rt_render_sync(g->members[i]); });
+}
+int rt_group_download_film(rt_group *g, double *spectrum_img)
+{
+	if (!g || !spectrum_img) return RT_ERR_INVALID;
+	if (int rc = rt_group_render_sync(g)) return rc;
+	if (int rc = group_sum_films(g)) return rc;
+	rt_context *root = g->members[0];
+	std::string err;
+	if (render_download_film(root->render, spectrum_img, root->stream, err, g->d_sum) != hipSuccess) return group_fail(g, RT_ERR_HIP, err);
+	return RT_OK;
+}
+int rt_group_download_preview(rt_group *g, int samples_done, double *preview_img)
+{
+	if (!g || !preview_img) return RT_ERR_INVALID;
+	if (int rc = rt_group_render_sync(g)) return rc;
+	if (int rc = group_sum_films(g)) return rc;
+	rt_context *root = g->members[0];
+	std::string err;
+	if (render_download_preview(root->render, samples_done, preview_img, root->stream, err, g->d_sum) != hipSuccess) return group_fail(g, RT_ERR_HIP, err);
+	return RT_OK;
+}
 
 int rt_profile_start(rt_context *ctx)
 {

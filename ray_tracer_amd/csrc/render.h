@@ -100,8 +100,11 @@ hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, i
 hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err);
 // runs the paths that render_pass left for its next batch to completion (a no-op when there are none)
 hipError_t render_flush(RenderState &rs, const DeviceGeom &geom, hipStream_t stream, std::string &err);
-hipError_t render_download_film(RenderState &rs, double *out, hipStream_t stream, std::string &err);
-hipError_t render_download_preview(RenderState &rs, int samples_done, double *out, hipStream_t stream, std::string &err);
+// film: another film of the same size on the same device to read instead of the context's own (the sum over a group of contexts)
+hipError_t render_download_film(RenderState &rs, double *out, hipStream_t stream, std::string &err, const float *film = nullptr);
+hipError_t render_download_preview(RenderState &rs, int samples_done, double *out, hipStream_t stream, std::string &err, const float *film = nullptr);
+// dst += src over n film elements (both on the current device)
+hipError_t render_accumulate_film(float *dst, const float *src, size_t n, hipStream_t stream);
 void render_free(RenderState &rs);
 
 } // namespace mi355rt

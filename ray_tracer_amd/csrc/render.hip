@@ -1788,12 +1788,28 @@ hipError_t render_flush(RenderState &rs, const DeviceGeom &geom, hipStream_t str
 	}
 }
 
-hipError_t render_download_film(RenderState &rs, double *out, hipStream_t stream, std::string &err)
+namespace {
+__global__ void __launch_bounds__(kBlock) k_film_accumulate(float *__restrict__ dst, const float *__restrict__ src, uint64_t n)
+{
+	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (idx < n) dst[idx] += src[idx];
+}
+} // namespace
+
+// dst += src over n film elements (both on the current device), on `stream`
+hipError_t render_accumulate_film(float *dst, const float *src, size_t n, hipStream_t stream)
+{
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_film_accumulate, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, dst, src, (uint64_t)n);
+	return hipGetLastError();
+}
+
+hipError_t render_download_film(RenderState &rs, double *out, hipStream_t stream, std::string &err, const float *film)
 {
 	const size_t n = (size_t)rs.nx * rs.ny * RT_NBINS;
 	double *d_tmp = nullptr;
 	HIP_TRY(hipMalloc((void **)&d_tmp, n * sizeof(double)));
-	hipLaunchKernelGGL(k_film_to_f64, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rs.d_film, (uint64_t)n, d_tmp);
+	hipLaunchKernelGGL(k_film_to_f64, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, film ? film : rs.d_film, (uint64_t)n, d_tmp);
 	hipError_t e = hipMemcpyAsync(out, d_tmp, n * sizeof(double), hipMemcpyDeviceToHost, stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(stream);
 	(void)hipFree(d_tmp);
@@ -1801,13 +1817,13 @@ hipError_t render_download_film(RenderState &rs, double *out, hipStream_t stream
 	return e;
 }
 
-hipError_t render_download_preview(RenderState &rs, int samples_done, double *out, hipStream_t stream, std::string &err)
+hipError_t render_download_preview(RenderState &rs, int samples_done, double *out, hipStream_t stream, std::string &err, const float *film)
 {
 	const size_t npix = (size_t)rs.nx * rs.ny;
 	double *d_tmp = nullptr;
 	HIP_TRY(hipMalloc((void **)&d_tmp, npix * 3 * sizeof(double)));
 	const float scale = (float)((double)rs.ns / (double)std::max(samples_done, 1)); // renderer.cpp:131
-	hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rs.d_film, (uint64_t)npix, scale, d_tmp);
+	hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, film ? film : rs.d_film, (uint64_t)npix, scale, d_tmp);
 	hipError_t e = hipMemcpyAsync(out, d_tmp, npix * 3 * sizeof(double), hipMemcpyDeviceToHost, stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(stream);
 	(void)hipFree(d_tmp);

@@ -10,13 +10,23 @@ Renderer::Renderer(void) // renderer.cpp:12-16
 {
 	std::random_device rd;
 	seed = ((unsigned long long)rd() << 32) | rd();
-	if (rt_create(0, &gpu) != RT_OK) {
-		last_error = rt_last_error(nullptr);
-		std::fprintf(stderr, "%s\n", last_error.c_str());
-	}
+	UseDevices({0});
 }
 
-Renderer::~Renderer() { rt_destroy(gpu); }
+Renderer::~Renderer() { rt_group_destroy(gpu); }
+
+bool Renderer::UseDevices(const std::vector<int> &devices)
+{
+	rt_group_destroy(gpu);
+	gpu = nullptr;
+	last_error.clear();
+	if (rt_group_create(devices.data(), (int)devices.size(), &gpu) != RT_OK) {
+		last_error = rt_group_last_error(nullptr);
+		std::fprintf(stderr, "%s\n", last_error.c_str());
+		return false;
+	}
+	return true;
+}
 
 void Renderer::Load(const char *objfilename) // renderer.cpp:18-22 (the parser's bool is ignored there too)
 {
@@ -54,8 +64,8 @@ bool Renderer::Upload(void)
 	rt_mesh m{tables.v.data(), tables.v.size() / 3, tables.vt.data(), tables.vt.size() / 3, tables.vn.data(), tables.vn.size() / 3,
 	          tables.corners.data(), tables.face_begin.data(), tables.face_begin.size() - 1, tables.object_begin.data(),
 	          (uint32_t)(tables.object_begin.size() - 1)};
-	if (!gpu || rt_upload_mesh(gpu, &m) != RT_OK) {
-		last_error = gpu ? rt_last_error(gpu) : rt_last_error(nullptr);
+	if (!gpu || rt_group_upload_mesh(gpu, &m) != RT_OK) {
+		last_error = rt_group_last_error(gpu);
 		std::fprintf(stderr, "%s\n", last_error.c_str());
 		return false;
 	}
@@ -76,19 +86,19 @@ bool Renderer::LoadMaterials(const std::map<std::string, std::shared_ptr<NodeMat
 		itr->second->EmitGraph((uint32_t)i, graphs); // per-hit program when the albedo / color slot reads the texture coordinate
 	}
 	if (!gpu) return false;
-	int rc = rt_upload_materials(gpu, recs.data(), (uint32_t)recs.size());
+	int rc = rt_group_upload_materials(gpu, recs.data(), (uint32_t)recs.size());
 	if (rc == RT_OK && !graphs.programs.empty()) {
 		rt_material_graphs view = graphs.View();
-		rc = rt_upload_material_graphs(gpu, &view);
+		rc = rt_group_upload_material_graphs(gpu, &view);
 	}
-	if (rc != RT_OK) last_error = rt_last_error(gpu);
+	if (rc != RT_OK) last_error = rt_group_last_error(gpu);
 	return rc == RT_OK; // RT_ERR_NO_LIGHTS: `light_objects.size() == 0` in the reference
 }
 
 bool Renderer::SetEnvironment(const uint8_t *texels, int width, int height, int bpp, double brightness)
 {
-	if (!gpu || rt_set_environment(gpu, texels, width, height, bpp, brightness) != RT_OK) {
-		last_error = gpu ? rt_last_error(gpu) : "no device";
+	if (!gpu || rt_group_set_environment(gpu, texels, width, height, bpp, brightness) != RT_OK) {
+		last_error = gpu ? rt_group_last_error(gpu) : "no device";
 		return false;
 	}
 	return true;
@@ -108,9 +118,9 @@ void Renderer::RenderImage(int nx, int ny, int ns, int spectral_samples, bool, b
 	preview_img.assign((size_t)nx * ny, dvec3());
 	rendering_runnnig = true;
 	rt_camera c = cam.Pod();
-	if (!gpu || rt_set_camera(gpu, &c) != RT_OK ||
-	    rt_render_begin(gpu, nx, ny, ns, spectral_samples, (int)algorithm_type, seed, nullptr) != RT_OK) {
-		last_error = gpu ? rt_last_error(gpu) : "no device";
+	if (!gpu || rt_group_set_camera(gpu, &c) != RT_OK ||
+	    rt_group_render_begin(gpu, nx, ny, ns, spectral_samples, (int)algorithm_type, seed) != RT_OK) {
+		last_error = gpu ? rt_group_last_error(gpu) : "no device";
 		std::fprintf(stderr, "%s\n", last_error.c_str());
 		rendering_runnnig = false;
 		return;
@@ -120,14 +130,14 @@ void Renderer::RenderImage(int nx, int ny, int ns, int spectral_samples, bool, b
 	while (s < ns) {
 		if (stop_rendering) break; // once per pass, renderer.cpp:70
 		int b = std::min(std::max(1, samples_per_pass), ns - s);
-		if (rt_render_pass(gpu, s, b) != RT_OK) { // no sync here: the pass's last paths ride along with the next pass; the downloads finish them
-			last_error = rt_last_error(gpu);
+		if (rt_group_render_pass(gpu, s, b) != RT_OK) { // no sync here: the pass's last paths ride along with the next pass; the downloads finish them
+			last_error = rt_group_last_error(gpu);
 			std::fprintf(stderr, "%s\n", last_error.c_str());
 			break;
 		}
 		s += b;
 		if (preview_img_flag || s == ns) { // renderer.cpp:124-143
-			rt_download_preview(gpu, s, prev.data());
+			rt_group_download_preview(gpu, s, prev.data());
 			for (size_t p = 0; p < (size_t)nx * ny; p++) preview_img[p] = dvec3(prev[3 * p], prev[3 * p + 1], prev[3 * p + 2]);
 			img_updated = true;
 		}
@@ -135,7 +145,7 @@ void Renderer::RenderImage(int nx, int ny, int ns, int spectral_samples, bool, b
 		if (print_progress) std::cout << progress * 100.0 << "%" << std::endl;
 	}
 	std::vector<double> film((size_t)nx * ny * RT_NBINS);
-	rt_download_film(gpu, film.data());
+	rt_group_download_film(gpu, film.data());
 	for (size_t p = 0; p < (size_t)nx * ny; p++)
 		for (int k = 0; k < RT_NBINS; k++) spectrum_img[p].data[k] = film[p * RT_NBINS + k];
 	img_updated = true;

@@ -23,6 +23,10 @@ class Renderer {
 public:
 	Renderer(void);
 	~Renderer();
+	// addition: render on several GPUs of the node (ordinals may repeat).  The reference's one parallel construct is the OpenMP loop
+	// over image columns (renderer.cpp:74-77); here every listed device renders its share of each pass's samples and the films are
+	// summed when they are read.  Call before Load; the default is device 0 alone.  False (and last_error) when a device is unusable.
+	bool UseDevices(const std::vector<int> &devices);
 	void Load(const char *objfilename);
 	// addition (the reference parses PLY files but never renders them, object.cpp:153-233): the file becomes one more
 	// object called `object_name`, appended to what Load / earlier LoadPly calls brought in; false on a parse error
@@ -52,7 +56,7 @@ public:
 private:
 	bool Upload(void);
 	MeshTables tables;              // what the device holds: obj objects first, then one object per LoadPly call
-	rt_context *gpu = nullptr;
+	rt_group *gpu = nullptr;        // one context per device in use
 };
 
 } // namespace mi355host

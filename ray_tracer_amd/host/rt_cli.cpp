@@ -3,6 +3,7 @@
 //   rt_cli --obj scene.obj --materials materials.json --objmatmap map.json [--width W --height H --sample S]
 //          [--algorithm naive|nee|mis|bdpt|misbdpt] [--seed N] [--spectral 30] [--film out.f64] [--ppm out.ppm] [--records out.f64] [--graphs out.bin]
 //          [--ply mesh.ply --ply-object NAME --ply-normals auto|file|flat|smooth]   one more object from a PLY file
+//          [--devices 0,1,2,3]     render on several GPUs (ordinals may repeat), samples of each pass split between them
 //   rt_cli --ply mesh.ply --dump-ply out.bin       host only: the parsed tables (u64 nv, nf, ni, has_normals; f64 [nv][6];
 //                                                  u64 [nf+1]; i32 [ni]) for tests
 #include <cstdio>
@@ -16,7 +17,7 @@ using namespace mi355host;
 
 int main(int argc, char **argv)
 {
-	std::string objp, matp, mapp, film_out, ppm_out, rec_out, graphs_out, alg = "mis", plyp, ply_object = "ply", ply_normals = "auto", ply_dump;
+	std::string objp, matp, mapp, film_out, ppm_out, rec_out, graphs_out, alg = "mis", plyp, ply_object = "ply", ply_normals = "auto", ply_dump, devices;
 	int w = 64, h = 64, ns = 4, spectral = 30;
 	unsigned long long seed = 1;
 	for (int i = 1; i + 1 < argc; i += 2) {
@@ -27,7 +28,7 @@ int main(int argc, char **argv)
 		else if (k == "--seed") seed = std::strtoull(v.c_str(), nullptr, 10); else if (k == "--spectral") spectral = std::atoi(v.c_str());
 		else if (k == "--film") film_out = v; else if (k == "--ppm") ppm_out = v; else if (k == "--records") rec_out = v; else if (k == "--graphs") graphs_out = v;
 		else if (k == "--ply") plyp = v; else if (k == "--ply-object") ply_object = v; else if (k == "--ply-normals") ply_normals = v;
-		else if (k == "--dump-ply") ply_dump = v;
+		else if (k == "--dump-ply") ply_dump = v; else if (k == "--devices") devices = v;
 		else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
 	}
 	if (!ply_dump.empty()) {
@@ -81,6 +82,16 @@ int main(int argc, char **argv)
 		}
 		Renderer r;
 		if (!r.last_error.empty()) return 3;
+		if (!devices.empty()) {
+			std::vector<int> list;
+			for (size_t at = 0; at < devices.size();) {
+				size_t comma = devices.find(',', at);
+				if (comma == std::string::npos) comma = devices.size();
+				list.push_back(std::atoi(devices.substr(at, comma - at).c_str()));
+				at = comma + 1;
+			}
+			if (!r.UseDevices(list)) return 3;
+		}
 		r.seed = seed;
 		r.Load(objp.c_str());
 		if (!plyp.empty()) {

@@ -78,3 +78,59 @@ def test_two_ranks_on_one_gpu_sum_to_the_single_context_film(tmp_path):
     assert abs(sum(o for _, _, o, _ in per_rank) - whole.sum()) <= 1e-5 * whole.sum()
     # fp32 atomics add in a different order in every run: equality up to rounding of the sums
     assert np.allclose(got, whole, rtol=1e-4, atol=1e-8)
+
+
+def test_group_of_contexts_renders_the_single_context_film():
+    """rt_group_*: three contexts (all on device 0 here; one per GPU on a node) split every pass's samples; the summed film and its
+    tonemap equal a single context's, for the unidirectional and the bidirectional integrator, in one pass or many"""
+    nx, ny, ns = 96, 54, 7
+    mesh, records, cam = scenes.cornell(nx, ny)
+    one = capi.Context(0)
+    grp = capi.Group([0, 0, 0])
+    assert grp.size() == 3
+    for c in (one, grp):
+        c.upload_mesh(mesh)
+        c.upload_materials(records)
+        c.set_camera(cam)
+    for alg in (capi.ALG_MIS, capi.ALG_NAIVE_BDPT):
+        one.render_begin(nx, ny, ns, 30, alg, 5)
+        one.render_pass(0, ns)
+        want, want_preview = one.download_film(), one.download_preview(ns)
+        grp.render_begin(nx, ny, ns, 30, alg, 5)
+        grp.render_pass(0, ns)
+        got = grp.download_film()
+        assert np.allclose(got, want, rtol=1e-4, atol=1e-8) and want.sum() > 0
+        assert np.allclose(grp.download_preview(ns), want_preview, atol=1e-5)
+        samples = [grp.member(i).stats()["camera_samples"] for i in range(3)]
+        assert samples == [3 * nx * ny, 2 * nx * ny, 2 * nx * ny]  # 7 samples over 3 members
+        grp.render_begin(nx, ny, ns, 30, alg, 5)
+        for s, n in ((0, 1), (1, 4), (5, 2)):  # passes smaller than the group: some members sit a pass out
+            grp.render_pass(s, n)
+        assert np.allclose(grp.download_film(), want, rtol=1e-4, atol=1e-8)
+    # failures name the member; the group stays usable
+    with pytest.raises(capi.BackendError) as e:
+        grp.upload_materials([dict(r, light_flag=False) for r in records])
+    assert e.value.code == capi.ERR_NO_LIGHTS and "member" in str(e.value)
+    with pytest.raises(capi.BackendError):
+        capi.Group([0, 99])
+    grp.upload_materials(records)
+    grp.render_begin(nx, ny, 2, 30, capi.ALG_NEE, 1)
+    grp.render_pass(0, 2)
+    assert grp.download_film().sum() > 0
+    grp.close()
+    one.close()
+
+
+def test_cpp_host_on_two_contexts_matches_one(tmp_path):
+    """the C++ host (Renderer::UseDevices through rt_cli --devices) on two contexts against the same program on one"""
+    cornell_dir = os.path.join(ROOT, "tests", "golden", "cornell")
+    cli = os.path.join(ROOT, "ray_tracer_amd", "lib", "rt_cli")
+    films = {}
+    for tag, extra in (("one", []), ("two", ["--devices", "0,0"])):
+        out = tmp_path / (tag + ".f64")
+        subprocess.run([cli, "--obj", os.path.join(cornell_dir, "cornell_box_triangulated.obj"), "--materials",
+                        os.path.join(cornell_dir, "materials.json"), "--objmatmap", os.path.join(cornell_dir, "objmatmap.json"),
+                        "--width", "64", "--height", "36", "--sample", "6", "--algorithm", "mis", "--seed", "9", "--film", str(out)] + extra,
+                       check=True, timeout=120)
+        films[tag] = np.fromfile(out, dtype=np.float64).reshape(-1, 30)
+    assert films["one"].sum() > 0 and np.allclose(films["one"], films["two"], rtol=1e-4, atol=1e-8)
