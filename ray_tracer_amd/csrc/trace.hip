@@ -101,6 +101,21 @@ __device__ __forceinline__ uint32_t permute_by_octant(uint32_t x, uint32_t oct)
 	return x;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with data-parallel-primitive moves: four shifted adds inside each row of 16
+// lanes, then the last lane of a row broadcast into the following rows (row_bcast:15 to rows 1 and 3, row_bcast:31 to rows 2 and 3).
+// Seven vector instructions and no LDS traffic, against six dependent ds_bpermute round trips for a shuffle-based scan.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+	int x = (int)v;
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); // row_shr:1
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); // row_shr:2
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); // row_shr:4
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); // row_shr:8
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+	return (uint32_t)x;
+}
+
 __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); } // v_cvt_f32_ubyteK
 
 // Persistent waves: each wave owns an interleaved share of the 64-ray chunks and keeps its 64 lanes busy by
@@ -312,13 +327,8 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				for (uint32_t h = l0_hits; h; h &= h - 1u) { const uint32_t c = (uint32_t)__ffs((int)h) - 1u; n_mine += (((c < 4 ? l0_m0 : l0_m1) >> (8 * (c & 3))) & 0xFFu) >> 5; }
 				for (uint32_t h = l1_hits; h; h &= h - 1u) { const uint32_t c = (uint32_t)__ffs((int)h) - 1u; n_mine += (((c < 4 ? l1_m0 : l1_m1) >> (8 * (c & 3))) & 0xFFu) >> 5; }
 			}
-			uint32_t incl = n_mine;
-#pragma unroll
-			for (int dlt = 1; dlt < 64; dlt <<= 1) {
-				const uint32_t up = (uint32_t)__shfl_up((int)incl, dlt);
-				if (lane >= dlt) incl += up;
-			}
-			const uint32_t off = incl - n_mine, total = (uint32_t)__shfl((int)incl, 63);
+			const uint32_t incl = wave_inclusive_sum(n_mine);
+			const uint32_t off = incl - n_mine, total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 			if (total != 0) {
 				const unsigned long long none_id = ~0ull;
 				unsigned long long my_t = (unsigned long long)__double_as_longlong(t_best);
