@@ -144,6 +144,15 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh);
  * environment variable MI355RT_BUILDER=host|device overrides it. */
 typedef enum rt_builder { RT_BUILDER_HOST_SAH = 0, RT_BUILDER_DEVICE_LBVH = 1, RT_BUILDER_AUTO = 2 } rt_builder;
 int rt_set_builder(rt_context *ctx, int builder);
+/* Which ray-triangle test the traversal kernels (and the direct light-polygon test of the NEE integrator) run; takes effect at once.
+ * RT_TRIANGLE_REFERENCE (default): ConvexPolygon::HitTriangle as the reference writes it (object.cpp:238-253) -- distance to the
+ *   plane of the polygon's first three vertices, three cross products, strict `> 0`: ids and t identical to the reference's
+ *   arithmetic, and like it not watertight (a ray through a shared edge or vertex can miss both neighbours).
+ * RT_TRIANGLE_WATERTIGHT: no counterpart in the reference.  Woop-Benthin-Wald edge functions in fp64 on every fan triangle's own
+ *   plane: no ray slips between triangles that share an edge, edges and vertices count as hits, and a hit always lies inside its
+ *   triangle's box, so results do not depend on the tree even for polygons that are not planar. */
+typedef enum rt_triangle_test { RT_TRIANGLE_REFERENCE = 0, RT_TRIANGLE_WATERTIGHT = 1 } rt_triangle_test;
+int rt_set_triangle_test(rt_context *ctx, int mode);
 /* Per-hit material graphs.  replaces: the Compute() chains that NodeMaterial::{SampleBSDF,BSDF,PDF,Emitted} run with
  * Argument{rec.vt} on every call (materialnode.cpp:1758-1795) when the albedo / color slot of a Lambertian, ColoredMetal or
  * DiffuseLight node is fed by nodes that read the hit's texture coordinate.  The host compiles such a graph to a postfix
@@ -252,6 +261,7 @@ int rt_group_upload_materials(rt_group *g, const rt_material *per_object, uint32
 int rt_group_upload_material_graphs(rt_group *g, const rt_material_graphs *graphs);
 int rt_group_set_environment(rt_group *g, const uint8_t *texels, int width, int height, int bpp, double brightness);
 int rt_group_set_camera(rt_group *g, const rt_camera *cam);
+int rt_group_set_triangle_test(rt_group *g, int mode);
 int rt_group_clear(rt_group *g);
 int rt_group_render_begin(rt_group *g, int nx, int ny, int ns, int spectral_samples, int algorithm, uint64_t seed);
 int rt_group_render_pass(rt_group *g, int first_sample, int n_samples);

@@ -524,6 +524,7 @@ struct orc_scene {
 	double *g_spectra, *g_vectors, *g_scalars;
 	uint32_t n_g_spectra, n_g_vectors, n_g_scalars, n_g_textures;
 	uint8_t **g_tex; int *g_tex_w, *g_tex_h, *g_tex_bpp;
+	int watertight;     /* 0: the reference's triangle test; 1: the optional watertight test (watertight_t) */
 	/* environment texture (globals of scene.h:20-22) */
 	uint8_t *env;
 	int env_w, env_h, env_bpp;
@@ -638,6 +639,8 @@ void orc_scene_polygon_bbox(const orc_scene *s, uint64_t poly, double minp[3], d
 	vstore(minp, s->poly_box[poly].minp);
 	vstore(maxp, s->poly_box[poly].maxp);
 }
+void orc_scene_set_triangle_test(orc_scene *s, int watertight) { s->watertight = watertight ? 1 : 0; }
+
 void orc_scene_get_triangles(const orc_scene *s, double *v9, double *nf3, uint32_t *poly)
 {
 	for (uint64_t f = 0; f < s->n_polys; f++) {
@@ -664,18 +667,57 @@ typedef struct {
 	int64_t tri;  /* which fan triangle accepted the hit */
 } hitrec;
 
-static inline int hit_triangle(v3 o, v3 d, double t_min, double t_max, v3 v0, v3 v1, v3 v2, v3 n0, v3 n1, v3 n2,
-                               v3 vt0, v3 vt1, v3 vt2, v3 face_normal, hitrec *rec) /* object.cpp:238-284 */
+/* The optional watertight triangle test (no counterpart in the reference, whose own test -- hit_triangle below -- leaks rays
+ * through shared edges and vertices: strict `> 0` on products of cross products).  Woop, Benthin, Wald, "Watertight Ray/Triangle
+ * Intersection" (JCGT 2013), in double precision without FMA contraction: translate the vertices to the ray origin, permute the
+ * axes so that the direction's largest component is z (swapping x and y when it is negative keeps the winding), shear the
+ * direction onto +z, and evaluate the three 2D edge functions.  An edge shared by two triangles yields the same products with
+ * the operands exchanged, i.e. exactly opposite values, so a ray cannot miss both; edges and vertices count as hits; no
+ * back-face culling (the reference has none).  t is the sheared z of the hit divided by the sum of the edge functions.
+ * The library's RT_TRIANGLE_WATERTIGHT mode computes exactly this, operation for operation. */
+static inline int watertight_t(v3 o, v3 d, double t_min, double t_max, v3 v0, v3 v1, v3 v2, double *t_out)
 {
-	double t = vdot(vsub(v0, o), face_normal) / vdot(d, face_normal);
+	const double ax = fabs(d.e[0]), ay = fabs(d.e[1]), az = fabs(d.e[2]);
+	int kz = ax > ay ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+	int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+	if (d.e[kz] < 0.0) { int tmp = kx; kx = ky; ky = tmp; }
+	const double sx = d.e[kx] / d.e[kz], sy = d.e[ky] / d.e[kz], sz = 1.0 / d.e[kz];
+	const v3 A = vsub(v0, o), B = vsub(v1, o), C = vsub(v2, o);
+	const double Ax = A.e[kx] - sx * A.e[kz], Ay = A.e[ky] - sy * A.e[kz];
+	const double Bx = B.e[kx] - sx * B.e[kz], By = B.e[ky] - sy * B.e[kz];
+	const double Cx = C.e[kx] - sx * C.e[kz], Cy = C.e[ky] - sy * C.e[kz];
+	const double U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+	if ((U < 0.0 || V < 0.0 || W < 0.0) && (U > 0.0 || V > 0.0 || W > 0.0))
+		return 0;
+	const double det = U + V + W;
+	if (det == 0.0)
+		return 0;
+	const double Az = sz * A.e[kz], Bz = sz * B.e[kz], Cz = sz * C.e[kz];
+	const double t = (U * Az + V * Bz + W * Cz) / det;
 	if (!(t >= t_min && t <= t_max))
 		return 0;
+	*t_out = t;
+	return 1;
+}
+
+static inline int hit_triangle(v3 o, v3 d, double t_min, double t_max, v3 v0, v3 v1, v3 v2, v3 n0, v3 n1, v3 n2,
+                               v3 vt0, v3 vt1, v3 vt2, v3 face_normal, hitrec *rec, int watertight) /* object.cpp:238-284 */
+{
+	double t;
+	if (watertight) {
+		if (!watertight_t(o, d, t_min, t_max, v0, v1, v2, &t))
+			return 0;
+	} else {
+		t = vdot(vsub(v0, o), face_normal) / vdot(d, face_normal);
+		if (!(t >= t_min && t <= t_max))
+			return 0;
+	}
 	v3 p = vadd(o, vscale(t, d)); /* ray.h:26-28 */
 	double tri_area = vlen(vcross(vsub(v1, v0), vsub(v2, v1)));
 	v3 result0 = vcross(vsub(v1, v0), vsub(p, v1));
 	v3 result1 = vcross(vsub(v2, v1), vsub(p, v2));
 	v3 result2 = vcross(vsub(v0, v2), vsub(p, v0));
-	if (vdot(result0, result1) > 0.0 && vdot(result1, result2) > 0.0) {
+	if (watertight || (vdot(result0, result1) > 0.0 && vdot(result1, result2) > 0.0)) {
 		rec->t = t;
 		rec->p = p;
 		rec->normal = vdiv(vadd(vadd(vscale(vlen(result1), n0), vscale(vlen(result2), n1)), vscale(vlen(result0), n2)), tri_area);
@@ -688,15 +730,23 @@ static inline int hit_triangle(v3 o, v3 d, double t_min, double t_max, v3 v0, v3
 static inline int polygon_hit(const orc_scene *s, uint64_t f, v3 o, v3 d, double t_min, double t_max, hitrec *rec) /* :286-305 */
 {
 	uint64_t b = s->poly_begin[f], n = s->poly_begin[f + 1] - b;
+	int found = 0;
 	for (uint64_t i = 1; i + 1 < n; i++) {
+		hitrec cand;
 		if (hit_triangle(o, d, t_min, t_max, s->pv[b], s->pv[b + i], s->pv[b + i + 1], s->pn[b], s->pn[b + i],
-		                 s->pn[b + i + 1], s->pvt[b], s->pvt[b + i], s->pvt[b + i + 1], s->face_normal[f], rec)) {
-			rec->poly = (int64_t)f;
-			rec->tri = (int64_t)(s->tri_begin[f] + i - 1);
-			return 1;
+		                 s->pn[b + i + 1], s->pvt[b], s->pvt[b + i], s->pvt[b + i + 1], s->face_normal[f], &cand, s->watertight)) {
+			cand.poly = (int64_t)f;
+			cand.tri = (int64_t)(s->tri_begin[f] + i - 1);
+			if (!s->watertight) { /* the reference: the first fan triangle that accepts wins (all share one plane distance) */
+				*rec = cand;
+				return 1;
+			}
+			/* watertight mode: every fan triangle has its own plane, a warped polygon can be met twice: the nearest counts */
+			if (!found || cand.t < rec->t) *rec = cand;
+			found = 1;
 		}
 	}
-	return 0;
+	return found;
 }
 
 int orc_polygon_hit(const orc_scene *s, uint64_t poly, const double o[3], const double d[3], double t_min, double t_max,
@@ -997,7 +1047,7 @@ uint64_t orc_trace_bvh2(const orc_scene *s, const void *nodes_v, uint64_t n_node
 					hitrec rec;
 					ntt++;
 					if (hit_triangle(o, d, t_min, t_best, s->pv[b], s->pv[b + fi], s->pv[b + fi + 1], s->pn[b],
-					                 s->pn[b + fi], s->pn[b + fi + 1], s->pvt[b], s->pvt[b + fi], s->pvt[b + fi + 1], s->face_normal[f], &rec)) {
+					                 s->pn[b + fi], s->pn[b + fi + 1], s->pvt[b], s->pvt[b + fi], s->pvt[b + fi + 1], s->face_normal[f], &rec, s->watertight)) {
 						if (best_tri < 0 || rec.t < t_best || (int64_t)t < best_tri) { /* tie -> lowest fan triangle */
 							best = rec;
 							best.poly = (int64_t)f;
@@ -1089,7 +1139,7 @@ uint64_t orc_trace_wide(const orc_scene *s, const void *nodes_v, uint64_t n_node
 					hitrec rec;
 					ntt++;
 					if (hit_triangle(o, d, t_min, t_best, s->pv[b], s->pv[b + fi], s->pv[b + fi + 1], s->pn[b],
-					                 s->pn[b + fi], s->pn[b + fi + 1], s->pvt[b], s->pvt[b + fi], s->pvt[b + fi + 1], s->face_normal[f], &rec)) {
+					                 s->pn[b + fi], s->pn[b + fi + 1], s->pvt[b], s->pvt[b + fi], s->pvt[b + fi + 1], s->face_normal[f], &rec, s->watertight)) {
 						if (best_tri < 0 || rec.t < t_best || (int64_t)t < best_tri) { /* tie -> lowest fan triangle */
 							best = rec;
 							best.poly = (int64_t)f;

@@ -131,6 +131,10 @@ uint64_t orc_trace_wide(const orc_scene *s, const void *nodes, uint64_t n_nodes,
                         const float *rays, uint64_t n, int32_t *out_poly, int32_t *out_tri, double *out_t,
                         uint64_t *node_visits, uint64_t *tri_tests, int nthreads);
 
+/* 0 (default): ConvexPolygon::HitTriangle as the reference writes it; 1: the optional watertight test of the library's
+ * RT_TRIANGLE_WATERTIGHT mode (no reference counterpart), used by every traversal and integrator of this file from then on */
+void orc_scene_set_triangle_test(orc_scene *s, int watertight);
+
 /* ---------------- materials (flat table, one record per object) ---------------- */
 enum { ORC_MAT_NONE = 0, ORC_MAT_LAMBERTIAN = 1, ORC_MAT_DIFFUSE_LIGHT = 2, ORC_MAT_DIELECTRIC = 3,
        ORC_MAT_CONDUCTOR = 4, ORC_MAT_COLORED_METAL = 5 };

@@ -11,13 +11,14 @@ BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH, BUILDER_AUTO = 0, 1, 2
 MAT_NONE, MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_COLORED_METAL = range(6)
 ALG_NAIVE, ALG_NEE, ALG_MIS, ALG_NAIVE_BDPT, ALG_MIS_BDPT = 0, 1, 2, 3, 4
 STATIC_MAX_RAYS = 1 << 20
+TRIANGLE_REFERENCE, TRIANGLE_WATERTIGHT = 0, 1
 
 # MI355RT_LIB names another build of the same library (kernel experiments: tools/bench_trace.py); there is still no fallback
 LIB_PATH = os.environ.get("MI355RT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmi355rt.so")
 
 # every symbol include/mi355rt.h declares
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_environment", "rt_upload_materials", "rt_upload_material_graphs", "rt_set_camera", "rt_clear",
+    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_triangle_test", "rt_group_set_triangle_test", "rt_set_environment", "rt_upload_materials", "rt_upload_material_graphs", "rt_set_camera", "rt_clear",
     "rt_trace_closest", "rt_trace_closest_static", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
     "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
     "rt_group_create", "rt_group_destroy", "rt_group_last_error", "rt_group_size", "rt_group_context", "rt_group_upload_mesh",
@@ -106,6 +107,8 @@ def load():
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_upload_mesh.argtypes = [vp, C.POINTER(Mesh)]
     lib.rt_set_builder.argtypes = [vp, C.c_int]
+    lib.rt_set_triangle_test.argtypes = [vp, C.c_int]
+    lib.rt_group_set_triangle_test.argtypes = [vp, C.c_int]
     lib.rt_upload_material_graphs.argtypes = [vp, vp]
     lib.rt_filter_bilateral.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]
     lib.rt_filter_bilateral_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]
@@ -200,6 +203,10 @@ class Context:
     def set_builder(self, builder):
         """BUILDER_HOST_SAH (default) or BUILDER_DEVICE_LBVH for the next upload_mesh"""
         self._check(self.lib.rt_set_builder(self.h, int(builder)))
+
+    def set_triangle_test(self, mode):
+        """TRIANGLE_REFERENCE (default: the reference's own test, not watertight) or TRIANGLE_WATERTIGHT"""
+        self._check(self.lib.rt_set_triangle_test(self.h, int(mode)))
 
     def set_environment(self, texels, brightness=0.5):
         """texels: uint8 [height, width, 3 or 4] (None removes the environment); brightness: env_brightness (scene.cpp:32)"""

@@ -239,6 +239,7 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	ctx->geom.face_object = (const uint32_t *)ctx->d_face_object;
 	ctx->geom.n_tris = (uint32_t)nt;
 	ctx->geom.depth = ctx->wide.depth;
+	ctx->geom.watertight = ctx->triangle_test == RT_TRIANGLE_WATERTIGHT ? 1u : 0u;
 	hipError_t e = render_upload_scene(ctx->render, hs, tri_leaf, ctx->geom.tri_face, ctx->geom.face_object, ctx->stream, err);
 	if (e != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	ctx->has_mesh = true;
@@ -250,6 +251,17 @@ int rt_set_builder(rt_context *ctx, int builder)
 	if (!ctx) return RT_ERR_INVALID;
 	if (builder != RT_BUILDER_HOST_SAH && builder != RT_BUILDER_DEVICE_LBVH && builder != RT_BUILDER_AUTO) return set_err(ctx, RT_ERR_INVALID, "rt_set_builder: unknown builder");
 	ctx->builder = builder;
+	return RT_OK;
+}
+
+int rt_set_triangle_test(rt_context *ctx, int mode)
+{
+	if (!ctx) return RT_ERR_INVALID;
+	if (mode != RT_TRIANGLE_REFERENCE && mode != RT_TRIANGLE_WATERTIGHT) return set_err(ctx, RT_ERR_INVALID, "rt_set_triangle_test: unknown mode");
+	if (!use_device(ctx)) return RT_ERR_HIP;
+	if (int rc = finish_pending_paths(ctx)) return rc; // paths in flight finish under the test they started with
+	ctx->triangle_test = mode;
+	ctx->geom.watertight = mode == RT_TRIANGLE_WATERTIGHT ? 1u : 0u;
 	return RT_OK;
 }
 
@@ -745,6 +757,11 @@ int rt_group_set_camera(rt_group *g, const rt_camera *cam)
 {
 	if (!g) return RT_ERR_INVALID;
 	return for_each_member(g, [&](size_t i) { return rt_set_camera(g->members[i], cam); });
+}
+int rt_group_set_triangle_test(rt_group *g, int mode)
+{
+	if (!g) return RT_ERR_INVALID;
+	return for_each_member(g, [&](size_t i) { return rt_set_triangle_test(g->members[i], mode); });
 }
 int rt_group_clear(rt_group *g)
 {

@@ -20,6 +20,7 @@ struct rt_context {
 	mi355rt::BvhWide wide; // the tree the device walks
 	bool has_mesh = false, has_materials = false, has_camera = false;
 	int builder = RT_BUILDER_AUTO;
+	int triangle_test = RT_TRIANGLE_REFERENCE;
 	bool built_on_device = false;
 	uint64_t device_nodes = 0;     // nodes of the tree in HBM
 

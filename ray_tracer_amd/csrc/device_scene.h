@@ -26,6 +26,7 @@ struct DeviceGeom {
 	const uint32_t *face_object; // face -> obj object
 	uint32_t n_tris;
 	uint32_t depth;
+	uint32_t watertight;         // 0: the reference's triangle test; 1: the watertight test (rt_set_triangle_test)
 };
 
 } // namespace mi355rt

@@ -935,6 +935,29 @@ __device__ bool face_hit_exact(const DeviceGeom &g, const DeviceShade &sh, uint3
 		const double2 a0 = rec[0], a1 = rec[1], a2 = rec[2], b0 = rec[3], b1 = rec[4], b2 = rec[5];
 		const double v0x = a0.x, v0y = a0.y, v0z = a1.x, nx = a1.y, ny = a2.x, nz = a2.y;
 		const double v1x = b0.x, v1y = b0.y, v1z = b1.x, v2x = b1.y, v2y = b2.x, v2z = b2.y;
+		if (g.watertight) { // the watertight test of trace.hip (watertight_t), same operations in the same order
+			const double ax_ = fabs(dx), ay_ = fabs(dy), az_ = fabs(dz);
+			const int kz = ax_ > ay_ ? (ax_ > az_ ? 0 : 2) : (ay_ > az_ ? 1 : 2);
+			const double dkz = kz == 0 ? dx : (kz == 1 ? dy : dz);
+			int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+			if (dkz < 0.0) { const int tmp = kx; kx = ky; ky = tmp; }
+#define PICK(k, x, y, z) ((k) == 0 ? (x) : ((k) == 1 ? (y) : (z)))
+			const double sx = PICK(kx, dx, dy, dz) / dkz, sy = PICK(ky, dx, dy, dz) / dkz, sz = 1.0 / dkz;
+			const double a0_ = v0x - ox, a1_ = v0y - oy, a2_ = v0z - oz, b0_ = v1x - ox, b1_ = v1y - oy, b2_ = v1z - oz;
+			const double c0_ = v2x - ox, c1_ = v2y - oy, c2_ = v2z - oz;
+			const double akz = PICK(kz, a0_, a1_, a2_), bkz = PICK(kz, b0_, b1_, b2_), ckz = PICK(kz, c0_, c1_, c2_);
+			const double Ax = PICK(kx, a0_, a1_, a2_) - sx * akz, Ay = PICK(ky, a0_, a1_, a2_) - sy * akz;
+			const double Bx = PICK(kx, b0_, b1_, b2_) - sx * bkz, By = PICK(ky, b0_, b1_, b2_) - sy * bkz;
+			const double Cx = PICK(kx, c0_, c1_, c2_) - sx * ckz, Cy = PICK(ky, c0_, c1_, c2_) - sy * ckz;
+#undef PICK
+			const double U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+			if ((U < 0.0 || V < 0.0 || W < 0.0) && (U > 0.0 || V > 0.0 || W > 0.0)) continue;
+			const double det = U + V + W;
+			if (det == 0.0) continue;
+			const double tw = (U * (sz * akz) + V * (sz * bkz) + W * (sz * ckz)) / det;
+			if (tw >= tmin && tw <= tmax) return true;
+			continue;
+		}
 		const double num = (v0x - ox) * nx + (v0y - oy) * ny + (v0z - oz) * nz;
 		const double den = dx * nx + dy * ny + dz * nz;
 		const double tt = num / den;

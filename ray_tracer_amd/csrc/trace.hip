@@ -76,6 +76,56 @@ __device__ __forceinline__ bool inside_exact(const RayD &r, double t, double v0x
 	return d12 > 0.0;
 }
 
+// The optional watertight test (rt_set_triangle_test; no counterpart in the reference): Woop, Benthin, Wald, "Watertight
+// Ray/Triangle Intersection" (JCGT 2013) in fp64 without FMA contraction.  The vertices are translated to the ray origin, the axes
+// permuted so that the direction's largest component is z, the direction sheared onto +z, and the three 2D edge functions
+// evaluated.  The edge two triangles share gives both the same two products, subtracted the other way round: exactly opposite
+// values, so no ray slips between them.  Edges and vertices hit, nothing is culled by orientation, t is the sheared depth.
+__device__ __forceinline__ bool watertight_t(const RayD &r, double tmax, double v0x, double v0y, double v0z, double v1x, double v1y,
+                                             double v1z, double v2x, double v2y, double v2z, double &t_out)
+{
+#pragma clang fp contract(off)
+	const double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
+	const int kz = ax > ay ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+	const double dkz = kz == 0 ? r.dx : (kz == 1 ? r.dy : r.dz);
+	int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+	if (dkz < 0.0) { const int tmp = kx; kx = ky; ky = tmp; }
+#define PICK(k, x, y, z) ((k) == 0 ? (x) : ((k) == 1 ? (y) : (z)))
+	const double dkx = PICK(kx, r.dx, r.dy, r.dz), dky = PICK(ky, r.dx, r.dy, r.dz);
+	const double sx = dkx / dkz, sy = dky / dkz, sz = 1.0 / dkz;
+	const double a0 = v0x - r.ox, a1 = v0y - r.oy, a2 = v0z - r.oz;
+	const double b0 = v1x - r.ox, b1 = v1y - r.oy, b2 = v1z - r.oz;
+	const double c0 = v2x - r.ox, c1 = v2y - r.oy, c2 = v2z - r.oz;
+	const double akz = PICK(kz, a0, a1, a2), bkz = PICK(kz, b0, b1, b2), ckz = PICK(kz, c0, c1, c2);
+	const double Ax = PICK(kx, a0, a1, a2) - sx * akz, Ay = PICK(ky, a0, a1, a2) - sy * akz;
+	const double Bx = PICK(kx, b0, b1, b2) - sx * bkz, By = PICK(ky, b0, b1, b2) - sy * bkz;
+	const double Cx = PICK(kx, c0, c1, c2) - sx * ckz, Cy = PICK(ky, c0, c1, c2) - sy * ckz;
+#undef PICK
+	const double U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+	if ((U < 0.0 || V < 0.0 || W < 0.0) && (U > 0.0 || V > 0.0 || W > 0.0)) return false;
+	const double det = U + V + W;
+	if (det == 0.0) return false;
+	const double Az = sz * akz, Bz = sz * bkz, Cz = sz * ckz;
+	const double t = (U * Az + V * Bz + W * Cz) / det;
+	if (!(t >= r.tmin && t <= tmax)) return false;
+	t_out = t;
+	return true;
+}
+
+// one (ray, triangle) test in either mode: the hit distance when the triangle is hit inside [tmin, tmax]
+template <bool WT>
+__device__ __forceinline__ bool triangle_test(const RayD &r, double tmax, const double2 &a0, const double2 &a1, const double2 &a2,
+                                              const double2 &b0, const double2 &b1, const double2 &b2, double &t_out)
+{
+	// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz); b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
+	if (WT) return watertight_t(r, tmax, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, t_out);
+	const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
+	if (!(t >= r.tmin && t <= tmax)) return false;
+	if (!inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) return false;
+	t_out = t;
+	return true;
+}
+
 __device__ __forceinline__ float next_up(float x) // smallest float > x for finite positive/negative x
 {
 	int i = __float_as_int(x);
@@ -127,7 +177,7 @@ __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return (floa
 // hits are kept as a parked group (triangle base + per-child counts + hit mask) while the lane goes on
 // descending; the fp64 triangle phase runs when a lane holds two parked groups or has run out of nodes,
 // so that it runs with most lanes holding work.
-template <bool LDS_STACK, bool ANY>
+template <bool LDS_STACK, bool ANY, bool WT>
 __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGeom g, const rt_ray *__restrict__ rays, uint64_t n_bound,
                                                   rt_hit *__restrict__ hits, double *__restrict__ t64,
                                                   uint8_t *__restrict__ any_out, const uint32_t *__restrict__ n_dev)
@@ -369,15 +419,13 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 						const double2 *rec = g.tri + (size_t)g.tri_stride * li; // one 128-byte line per triangle
 						const double2 a0 = rec[0], a1 = rec[1], a2 = rec[2], b0 = rec[3], b1 = rec[4], b2 = rec[5];
 						// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz); b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
-						const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
-						if (t >= r.tmin && t <= cur_best) {
+						double t;
+						if (triangle_test<WT>(r, cur_best, a0, a1, a2, b0, b1, b2, t)) {
 							TRACE_COUNT(st_in_iter, st_in_lanes);
-							if (inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) {
-								hit = true;
-								bits = (unsigned long long)__double_as_longlong(t + 0.0); // -0.0 -> +0.0: keeps bit order = numeric order
-								id = ANY ? 0ull : (((unsigned long long)reinterpret_cast<const uint4 *>(rec)[6].x << 32) | li);
-								__hip_atomic_fetch_min(&coop_t[wv][o], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-							}
+							hit = true;
+							bits = (unsigned long long)__double_as_longlong(t + 0.0); // -0.0 -> +0.0: keeps bit order = numeric order
+							id = ANY ? 0ull : (((unsigned long long)reinterpret_cast<const uint4 *>(rec)[6].x << 32) | li);
+							__hip_atomic_fetch_min(&coop_t[wv][o], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 						}
 					}
 					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -427,14 +475,10 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 						TRACE_COUNT(st_leaf_iter, st_leaf_lanes);
 						const uint32_t li = first + k;
 						const double2 *rec = g.tri + (size_t)g.tri_stride * li;
-						const double2 a0 = rec[0], a1 = rec[1], a2 = rec[2];
-						// a0 = (v0x, v0y), a1 = (v0z, nx), a2 = (ny, nz)
-						const double t = plane_t(r, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
-						if (!(t >= r.tmin && t <= t_best)) continue;
+						const double2 a0 = rec[0], a1 = rec[1], a2 = rec[2], b0 = rec[3], b1 = rec[4], b2 = rec[5];
+						double t;
+						if (!triangle_test<WT>(r, t_best, a0, a1, a2, b0, b1, b2, t)) continue;
 						TRACE_COUNT(st_in_iter, st_in_lanes);
-						const double2 b0 = rec[3], b1 = rec[4], b2 = rec[5];
-						// b0 = (v1x, v1y), b1 = (v1z, v2x), b2 = (v2y, v2z)
-						if (!inside_exact(r, t, a0.x, a0.y, a1.x, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y)) continue;
 						if (ANY) { found_any = true; break; }
 						const uint4 meta = reinterpret_cast<const uint4 *>(rec)[6];
 						const uint32_t tri = meta.x;
@@ -516,28 +560,30 @@ inline TraceGrid trace_grid(uint64_t n)
 
 } // namespace
 
-hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, hipStream_t stream, const uint32_t *d_n)
+namespace {
+template <bool ANY>
+hipError_t launch_trace(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, uint8_t *d_any, hipStream_t stream, const uint32_t *d_n)
 {
 	if (n == 0) return hipSuccess;
 	if (g.depth > (uint32_t)kScratchStack) return hipErrorInvalidValue;
 	const TraceGrid tg = trace_grid(n);
-	if (g.depth <= (uint32_t)kLdsStack)
-		hipLaunchKernelGGL((k_trace<true, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr, d_n);
-	else
-		hipLaunchKernelGGL((k_trace<false, false>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, (uint8_t *)nullptr, d_n);
+	const bool lds = g.depth <= (uint32_t)kLdsStack;
+#define TRACE_LAUNCH(L, W) hipLaunchKernelGGL((k_trace<L, ANY, W>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, d_any, d_n)
+	if (g.watertight) { if (lds) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(false, true); }
+	else { if (lds) TRACE_LAUNCH(true, false); else TRACE_LAUNCH(false, false); }
+#undef TRACE_LAUNCH
 	return hipGetLastError();
+}
+} // namespace
+
+hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, hipStream_t stream, const uint32_t *d_n)
+{
+	return launch_trace<false>(g, d_rays, n, d_hits, d_t64, nullptr, stream, d_n);
 }
 
 hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, uint8_t *d_out, hipStream_t stream, const uint32_t *d_n)
 {
-	if (n == 0) return hipSuccess;
-	if (g.depth > (uint32_t)kScratchStack) return hipErrorInvalidValue;
-	const TraceGrid tg = trace_grid(n);
-	if (g.depth <= (uint32_t)kLdsStack)
-		hipLaunchKernelGGL((k_trace<true, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out, d_n);
-	else
-		hipLaunchKernelGGL((k_trace<false, true>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, (rt_hit *)nullptr, (double *)nullptr, d_out, d_n);
-	return hipGetLastError();
+	return launch_trace<true>(g, d_rays, n, nullptr, nullptr, d_out, stream, d_n);
 }
 
 // ---- staging that needs no allocation (rt_trace_closest_static)

@@ -105,6 +105,7 @@ def lib():
         L.orc_trace_bvh2.restype = u64
         L.orc_trace_wide.argtypes = [vp, vp, u64, vp, vp, u64, vp, vp, vp, C.POINTER(u64), C.POINTER(u64), C.c_int]
         L.orc_trace_wide.restype = u64
+        L.orc_scene_set_triangle_test.argtypes = [vp, C.c_int]
         L.orc_scene_set_materials.argtypes = [vp, C.POINTER(OrcMaterial), C.c_uint32]
         L.orc_scene_n_lights.argtypes = [vp]
         L.orc_scene_n_lights.restype = u64
@@ -186,6 +187,10 @@ class Scene:
         lib().orc_trace_bvh2(self.h, _p(nodes), len(nodes), _p(tri_index), _p(rays), n, _p(poly), _p(tri), _p(t),
                              C.byref(nv), C.byref(nt), nthreads)
         return poly, tri, t, nv.value, nt.value
+
+    def set_triangle_test(self, watertight):
+        """False: the reference's triangle test; True: the optional watertight test (the library's RT_TRIANGLE_WATERTIGHT)"""
+        lib().orc_scene_set_triangle_test(self.h, 1 if watertight else 0)
 
     def trace_wide(self, nodes, tri_index, rays, nthreads=0):
         """ordered, pruned traversal over the product's 8-wide tree; returns poly, tri, t, nodes fetched, triangle records tested"""

@@ -1,6 +1,6 @@
 """A/B harness for the traversal kernels: closest-hit rate on the Cornell box's own render rays (cache-resident scene) and on the
 1M-triangle soup (memory-bound scene), with a checksum of the results so that variants can be compared for identical answers.
-usage: [MI355RT_LIB=path/to/libmi355rt.so] python tools/bench_trace.py [tag] [--soup10m]"""
+usage: [MI355RT_LIB=path/to/libmi355rt.so] python tools/bench_trace.py [tag] [--soup10m] [--watertight]"""
 import os
 import sys
 
@@ -12,6 +12,8 @@ from ray_tracer_amd import capi, scenes, synth
 
 tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else os.environ.get("MI355RT_LIB", "default")
 ctx = capi.Context(0)
+if "--watertight" in sys.argv:
+    ctx.set_triangle_test(capi.TRIANGLE_WATERTIGHT)
 
 
 def rate(rays, reps=5, any_hit=False):
