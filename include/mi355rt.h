@@ -72,14 +72,17 @@ typedef struct rt_mesh {
 
 /* BSDF node wired to a NodeMaterial's Output (materialnode.cpp:1758-1795), constant-folded to
  * 30-bin spectra by the host.  a/b: Lambertian a=albedo; DiffuseLight a=color; Dielectric a=n,
- * b=surface_color; Conductor a=n, b=k; ColoredMetal a=albedo. */
+ * b=surface_color; Conductor a=n, b=k; ColoredMetal a=albedo; GGX a=n, b=k (carried, not used: the node sets fresnel = 1). */
 typedef enum rt_material_type {
 	RT_MAT_NONE = 0,          /* nothing wired to "BSDF": SampleBSDF false, BSDF/PDF/Emitted 0 */
 	RT_MAT_LAMBERTIAN = 1,    /* materialnode.cpp:262-295 */
 	RT_MAT_DIFFUSE_LIGHT = 2, /* materialnode.cpp:739-749 */
 	RT_MAT_DIELECTRIC = 3,    /* materialnode.cpp:354-419 */
 	RT_MAT_CONDUCTOR = 4,     /* materialnode.cpp:473-514 */
-	RT_MAT_COLORED_METAL = 5  /* materialnode.cpp:564-596 */
+	RT_MAT_COLORED_METAL = 5, /* materialnode.cpp:564-596 */
+	RT_MAT_GGX = 6            /* GGXReflectionNode (materialnode.cpp:647-695) made well defined, a deviation: the reference reads an
+	                           * uninitialised alpha and returns nothing from BSDF() / PDF().  SampleBSDF as written there, in the
+	                           * shading frame, with alpha = `roughness`; BSDF() and PDF() are the same expressions for the half vector */
 } rt_material_type;
 
 typedef struct rt_material {
@@ -87,6 +90,7 @@ typedef struct rt_material {
 	int32_t light_flag; /* NodeMaterial::light_flag (materialnode.cpp:1613) */
 	double a[RT_NBINS];
 	double b[RT_NBINS];
+	double roughness;   /* RT_MAT_GGX: alpha, the node's "roughness" (0.5 when the file has none); ignored by the other types */
 } rt_material;
 
 /* LensCamera state after SetLens + set_Camera (camera.h:101-209), copied field by field. */

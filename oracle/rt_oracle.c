@@ -1262,9 +1262,28 @@ static double mat_emitted(const orc_material *m, const band *b) /* materialnode.
 	return 0.0;
 }
 
+/* GGXReflectionNode made well defined -- parity unpinned and a deviation: in the reference `alpha` is read uninitialised,
+ * BSDF() and PDF() return nothing, and dot(micro_normal, rec.normal) mixes a local with a world vector (materialnode.cpp:647-695).
+ * What is kept is SampleBSDF as written there with everything expressed in the shading frame (z = rec.normal): the micro-normal
+ * distribution d = alpha^2 x / (pi cos^4 (alpha^2 + tan^2)^2) with x = max(m.z, 0) (:669-675), pdf = d |m.z| / (4 |m.z|) (:676-677),
+ * BSDF = d / (4 |vi.z vo.z|) with fresnel = g = 1 (:665-666,682), ratio = |vo.m| / |vo.z vi.z m.z| (:686).  BSDF() and PDF() are
+ * defined as the same expressions for the half vector m = unit(vi + vo), and as 0 unless vi and vo lie on the same side of the
+ * surface (a reflection); a sampled direction that ends up on the other side carries no energy.  alpha comes from the material record. */
+static double ggx_d(double alpha, double cos_theta)
+{
+	if (!(cos_theta > 0.0)) return 0.0; /* x = 0 there: the numerator vanishes (and the denominator with it at the horizon) */
+	const double x = cos_theta;
+	const double cos2 = cos_theta * cos_theta, sin_theta = sqrt(1.0 - cos2 < 0.0 ? 0.0 : 1.0 - cos2), tan_theta = sin_theta / cos_theta;
+	return alpha * alpha * x / (M_PI * cos2 * cos2 * pow(alpha * alpha + tan_theta * tan_theta, 2));
+}
+static double ggx_half_z(v3 vi, v3 vo) { return fabs(vunit(vadd(vi, vo)).e[2]); } /* the half vector on the side of the normal */
+
 static double mat_bsdf(const orc_material *m, v3 vi, double wli, v3 vo)
 {
 	switch (m->type) {
+	case ORC_MAT_GGX:
+		if (!(vi.e[2] * vo.e[2] > 0.0)) return 0.0;
+		return ggx_d(m->roughness, ggx_half_z(vi, vo)) / (4.0 * fabs(vi.e[2] * vo.e[2]));
 	case ORC_MAT_LAMBERTIAN: /* materialnode.cpp:278-288 */
 		if (vi.e[2] < 0.0) return 0.0;
 		return orc_spectrum_get(m->a, wli) / M_PI;
@@ -1280,6 +1299,9 @@ static double mat_bsdf(const orc_material *m, v3 vi, double wli, v3 vo)
 static double mat_pdf(const orc_material *m, v3 vi, v3 vo)
 {
 	switch (m->type) {
+	case ORC_MAT_GGX:
+		if (!(vi.e[2] * vo.e[2] > 0.0)) return 0.0;
+		return ggx_d(m->roughness, ggx_half_z(vi, vo)) / 4.0;
 	case ORC_MAT_LAMBERTIAN: /* :289-295 */
 		if (vi.e[2] < 0.0) return 0.0;
 		return vi.e[2] / M_PI;
@@ -1348,6 +1370,22 @@ static int mat_sample_t(const orc_material *m, v3 normal, const onb *uvw, v3 vo,
 		*pdfval = INFINITY;
 		*bsdf = INFINITY;
 		*ratio = fresnel / cos_o;
+		return 1;
+	}
+	case ORC_MAT_GGX: { /* :647-689, see ggx_d */
+		const double alpha = m->roughness;
+		double phi = 2 * M_PI * orc_rng_f64(rng);
+		double u = orc_rng_f64(rng);
+		double cos_theta = sqrt((1.0 - u) / ((alpha * alpha - 1.0) * u + 1));
+		double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+		v3 mn = V(sin_theta * cos(phi), sin_theta * sin(phi), cos_theta);
+		double d = ggx_d(alpha, cos_theta);
+		double pm = d * fabs(mn.e[2]);
+		*vi = vadd(vneg(vo), vscale(2.0 * vdot(vo, mn), mn)); /* reflect2, material.cpp:98-101 */
+		*pdfval = pm / (4.0 * fabs(mn.e[2]));
+		*bsdf = d / (4.0 * fabs(vi->e[2] * vo.e[2]));
+		*ratio = fabs(vdot(vo, mn)) / fabs(vo.e[2] * vi->e[2] * mn.e[2]);
+		if (!(vi->e[2] * vo.e[2] > 0.0)) { *bsdf = 0.0; *ratio = 0.0; } /* reflected below the surface: no energy */
 		return 1;
 	}
 	case ORC_MAT_COLORED_METAL: /* :564-584 */

@@ -137,12 +137,13 @@ void orc_scene_set_triangle_test(orc_scene *s, int watertight);
 
 /* ---------------- materials (flat table, one record per object) ---------------- */
 enum { ORC_MAT_NONE = 0, ORC_MAT_LAMBERTIAN = 1, ORC_MAT_DIFFUSE_LIGHT = 2, ORC_MAT_DIELECTRIC = 3,
-       ORC_MAT_CONDUCTOR = 4, ORC_MAT_COLORED_METAL = 5 };
+       ORC_MAT_CONDUCTOR = 4, ORC_MAT_COLORED_METAL = 5, ORC_MAT_GGX = 6 };
 typedef struct orc_material {
 	int32_t type;
 	int32_t light_flag;                 /* NodeMaterial::light_flag, materialnode.cpp:1613 */
 	double a[ORC_NBINS];                /* albedo | color | n */
 	double b[ORC_NBINS];                /* k | surface_color */
+	double roughness;                   /* ORC_MAT_GGX: alpha (the reference never initialises its alpha, materialnode.cpp:651) */
 } orc_material;
 /* returns 0 when no light polygons exist (renderer.cpp:41-42) */
 /* BiliteralFilter::FilterImage (filter.cpp:13-51); pinned by the compiled reference (oracle/_ref/libref_filter.so) */

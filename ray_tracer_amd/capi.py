@@ -8,7 +8,7 @@ NBINS = 30
 MISS = 0xFFFFFFFF
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NO_LIGHTS, ERR_NO_MATERIAL, ERR_MESH = 0, -1, -2, -3, -4, -5, -6
 BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH, BUILDER_AUTO = 0, 1, 2
-MAT_NONE, MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_COLORED_METAL = range(6)
+MAT_NONE, MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_COLORED_METAL, MAT_GGX = range(7)
 ALG_NAIVE, ALG_NEE, ALG_MIS, ALG_NAIVE_BDPT, ALG_MIS_BDPT = 0, 1, 2, 3, 4
 STATIC_MAX_RAYS = 1 << 20
 TRIANGLE_REFERENCE, TRIANGLE_WATERTIGHT = 0, 1
@@ -44,7 +44,8 @@ class Mesh(C.Structure):
 
 
 class Material(C.Structure):
-    _fields_ = [("type", C.c_int32), ("light_flag", C.c_int32), ("a", C.c_double * NBINS), ("b", C.c_double * NBINS)]
+    _fields_ = [("type", C.c_int32), ("light_flag", C.c_int32), ("a", C.c_double * NBINS), ("b", C.c_double * NBINS),
+                ("roughness", C.c_double)]
 
 
 class Texture(C.Structure):
@@ -232,6 +233,7 @@ class Context:
         for i, m in enumerate(materials):
             arr[i].type = int(m["type"])
             arr[i].light_flag = int(bool(m["light_flag"]))
+            arr[i].roughness = float(m.get("roughness", 0.0))
             for k in range(NBINS):
                 arr[i].a[k] = float(m["a"][k])
                 arr[i].b[k] = float(m["b"][k])
@@ -438,6 +440,7 @@ class Group:
         for i, m in enumerate(materials):
             arr[i].type = int(m["type"])
             arr[i].light_flag = int(bool(m["light_flag"]))
+            arr[i].roughness = float(m.get("roughness", 0.0))
             for k in range(NBINS):
                 arr[i].a[k] = float(m["a"][k])
                 arr[i].b[k] = float(m["b"][k])

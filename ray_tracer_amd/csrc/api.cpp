@@ -273,8 +273,11 @@ int rt_upload_materials(rt_context *ctx, const rt_material *per_object, uint32_t
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	if (int rc = finish_pending_paths(ctx)) return rc;
 	for (uint32_t o = 0; o < n_objects; o++)
-		if (per_object[o].type < RT_MAT_NONE || per_object[o].type > RT_MAT_COLORED_METAL)
+		if (per_object[o].type < RT_MAT_NONE || per_object[o].type > RT_MAT_GGX)
 			return set_err(ctx, RT_ERR_INVALID, "rt_upload_materials: unknown material type");
+	for (uint32_t o = 0; o < n_objects; o++)
+		if (per_object[o].type == RT_MAT_GGX && !(per_object[o].roughness > 0.0 && per_object[o].roughness <= 1.0e3))
+			return set_err(ctx, RT_ERR_INVALID, "rt_upload_materials: a GGX record needs a roughness in (0, 1000]");
 	ctx->materials.assign(per_object, per_object + n_objects);
 	ctx->light_faces.clear();
 	for (uint32_t o = 0; o < n_objects; o++) // renderer.cpp:35-39

@@ -35,6 +35,7 @@ struct DevMaterial {
 	int type, light_flag;
 	float a[RT_NBINS], b[RT_NBINS];
 	uint32_t prog_begin, prog_len; // slot a (albedo / color) as a per-hit program when prog_len != 0
+	float roughness;               // RT_MAT_GGX: alpha
 };
 
 // One wavelength band of the pass loop (renderer.cpp:85-88) with everything that depends on it
@@ -347,12 +348,25 @@ __device__ __forceinline__ float mat_emitted(const DeviceShade &sh, const DevMat
 	return sum;
 }
 
+// RT_MAT_GGX: the micro-normal density of GGXReflectionNode::SampleBSDF (materialnode.cpp:669-675) as a function of the cosine between
+// micro-normal and shading normal, d = alpha^2 max(cos, 0) / (pi cos^4 (alpha^2 + tan^2)^2); BSDF = d / (4 |vi.z vo.z|), pdf = d / 4
+__device__ __forceinline__ float ggx_d(float alpha, float cos_theta)
+{
+	if (!(cos_theta > 0.0f)) return 0.0f;
+	const float x = cos_theta;
+	const float cos2 = cos_theta * cos_theta, sin_theta = sqrtf(fmaxf(1.0f - cos2, 0.0f)), tan_theta = sin_theta / cos_theta;
+	const float q = alpha * alpha + tan_theta * tan_theta;
+	return alpha * alpha * x / (kPi * cos2 * cos2 * (q * q));
+}
+__device__ __forceinline__ float ggx_half_z(f3 vi, f3 vo) { return fabsf(unit(vi + vo).z); }
+
 __device__ __forceinline__ bool mirror_pair(f3 vi, f3 vo) { return -vi.x == vo.x && -vi.y == vo.y && vi.z == vo.z; }
 
 // a: slot a of the material at this hit and bin (slot_a)
 __device__ __forceinline__ float mat_bsdf(const DevMaterial &m, f3 vi, f3 vo, float a)
 {
 	switch (m.type) {
+	case RT_MAT_GGX: return vi.z * vo.z > 0.0f ? ggx_d(m.roughness, ggx_half_z(vi, vo)) / (4.0f * fabsf(vi.z * vo.z)) : 0.0f; // a reflection or nothing
 	case RT_MAT_LAMBERTIAN: return vi.z < 0.0f ? 0.0f : a / kPi;                               // materialnode.cpp:278-288
 	case RT_MAT_CONDUCTOR:
 	case RT_MAT_COLORED_METAL: return mirror_pair(vi, vo) ? __int_as_float(0x7f800000) : 0.0f; // :503-508, :585-590
@@ -362,6 +376,7 @@ __device__ __forceinline__ float mat_bsdf(const DevMaterial &m, f3 vi, f3 vo, fl
 __device__ __forceinline__ float mat_pdf(const DevMaterial &m, f3 vi, f3 vo)
 {
 	switch (m.type) {
+	case RT_MAT_GGX: return vi.z * vo.z > 0.0f ? ggx_d(m.roughness, ggx_half_z(vi, vo)) / 4.0f : 0.0f;
 	case RT_MAT_LAMBERTIAN: return vi.z < 0.0f ? 0.0f : vi.z / kPi;                            // :289-295
 	case RT_MAT_CONDUCTOR:
 	case RT_MAT_COLORED_METAL: return mirror_pair(vi, vo) ? __int_as_float(0x7f800000) : 0.0f; // :509-514, :591-596
@@ -447,6 +462,18 @@ __device__ __forceinline__ bool mat_sample(const DevMaterial &m, f3 normal, cons
 		vi = F3(-vo.x, -vo.y, vo.z);
 		pdfval = __int_as_float(0x7f800000);
 		ratio = fresnel / cos_o;
+		return true;
+	}
+	case RT_MAT_GGX: { // :647-689 in the shading frame, alpha from the record (see ggx_d)
+		const float alpha = m.roughness;
+		const float r1 = rng_f32(rng), u = rng_f32(rng);
+		const float cos_theta = sqrtf((1.0f - u) / ((alpha * alpha - 1.0f) * u + 1.0f));
+		const float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+		const f3 mn = F3(sin_theta * __builtin_amdgcn_cosf(r1), sin_theta * __builtin_amdgcn_sinf(r1), cos_theta);
+		const float d = ggx_d(alpha, cos_theta);
+		vi = neg(vo) + (2.0f * dot(vo, mn)) * mn; // reflect2, material.cpp:98-101
+		pdfval = d * fabsf(mn.z) / (4.0f * fabsf(mn.z));
+		ratio = vi.z * vo.z > 0.0f ? fabsf(dot(vo, mn)) / fabsf(vo.z * vi.z * mn.z) : 0.0f; // reflected below the surface: no energy
 		return true;
 	}
 	case RT_MAT_COLORED_METAL: // :564-584
@@ -1265,6 +1292,7 @@ hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const
 		dm[i].light_flag = mats[i].light_flag;
 		for (int k = 0; k < RT_NBINS; k++) { dm[i].a[k] = (float)mats[i].a[k]; dm[i].b[k] = (float)mats[i].b[k]; }
 		dm[i].prog_begin = dm[i].prog_len = 0;
+		dm[i].roughness = (float)mats[i].roughness;
 	}
 	HIP_TRY(upload(im.materials, dm, stream));
 	im.host_materials = dm;

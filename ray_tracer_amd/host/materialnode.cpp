@@ -432,8 +432,14 @@ rt_material NodeMaterial::Record() const
 		bb = SlotSpectrum(b, "surface_color", "surface_color");
 	} else if (t == "Conductor") { r.type = RT_MAT_CONDUCTOR; a = own_array(nodes[b], "n"); bb = own_array(nodes[b], "k"); }
 	else if (t == "ColoredMetal") { r.type = RT_MAT_COLORED_METAL; a = slot_a("albedo"); }
-	else if (t == "GGXReflection")
-		throw UnsupportedMaterialGraph("GGXReflection reads an uninitialised alpha and returns no value from BSDF()/PDF() in the reference");
+	else if (t == "GGXReflection") {
+		// the reference reads an uninitialised alpha and returns no value from BSDF()/PDF() (materialnode.cpp:647-695): the backend
+		// runs a well-defined variant (RT_MAT_GGX) with alpha from the node's "roughness" key, 0.5 without one
+		r.type = RT_MAT_GGX;
+		a = own_array(nodes[b], "n");
+		bb = own_array(nodes[b], "k");
+		r.roughness = nodes[b].contains("roughness") ? nodes[b].at("roughness").number(0.5) : 0.5;
+	}
 	else throw UnsupportedMaterialGraph("node type " + t + " wired to the BSDF output of " + name);
 	for (int i = 0; i < N; i++) { r.a[i] = a[i]; r.b[i] = bb[i]; }
 	return r;

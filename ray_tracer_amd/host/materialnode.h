@@ -32,7 +32,7 @@ public:
 	explicit NodeMaterial(const Json &j);
 	std::string name;
 	bool light_flag = false;
-	// throws UnsupportedMaterialGraph for nodes that are not evaluated on the device (noise, rotation, component access, GGXReflection).
+	// throws UnsupportedMaterialGraph for nodes that are not evaluated on the device (nodes the device has no evaluator for).
 	// When the albedo / color slot depends on the texture coordinate, `a` is zero and EmitGraph supplies the program.
 	rt_material Record() const;
 	// appends this material's per-hit program for `object` to the tables; false when its slot is a constant.

@@ -62,6 +62,7 @@ int main(int argc, char **argv)
 				f.write((const char *)head, sizeof(head));
 				f.write((const char *)m.a, sizeof(m.a));
 				f.write((const char *)m.b, sizeof(m.b));
+				f.write((const char *)&m.roughness, sizeof(m.roughness));
 			}
 		}
 		if (!graphs_out.empty()) { // host logic only: the per-hit programs, as u64 counts (programs, code pairs, spectra, vectors, scalars),

@@ -748,8 +748,9 @@ class NodeMaterial:
         elif t == "ColoredMetal":
             rec.update(type=capi.MAT_COLORED_METAL, **slot_a("albedo"))
         elif t == "GGXReflection":
-            raise UnsupportedMaterialGraph("GGXReflection reads an uninitialised alpha and returns no value from "
-                                           "BSDF()/PDF() in the reference (materialnode.cpp:647-695)")
+            # the reference reads an uninitialised alpha and returns no value from BSDF()/PDF() (materialnode.cpp:647-695): the
+            # backend runs a well-defined variant (RT_MAT_GGX) with alpha from the node's "roughness" key, 0.5 without one
+            rec.update(type=capi.MAT_GGX, a=own("n"), b=own("k"), roughness=float(node.get("roughness", 0.5)))
         else:
             raise UnsupportedMaterialGraph("node type %s wired to the BSDF output of %s" % (t, self.name))
         return rec

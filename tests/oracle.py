@@ -26,7 +26,8 @@ class OrcCamera(C.Structure):
 
 
 class OrcMaterial(C.Structure):
-    _fields_ = [("type", C.c_int32), ("light_flag", C.c_int32), ("a", C.c_double * NBINS), ("b", C.c_double * NBINS)]
+    _fields_ = [("type", C.c_int32), ("light_flag", C.c_int32), ("a", C.c_double * NBINS), ("b", C.c_double * NBINS),
+                ("roughness", C.c_double)]
 
 
 class OrcStats(C.Structure):
@@ -210,6 +211,7 @@ class Scene:
         for i, m in enumerate(records):
             arr[i].type = int(m["type"])
             arr[i].light_flag = int(bool(m["light_flag"]))
+            arr[i].roughness = float(m.get("roughness", 0.0))
             for k in range(NBINS):
                 arr[i].a[k] = float(m["a"][k])
                 arr[i].b[k] = float(m["b"][k])
