@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W
 
 Workload (N=1): the Cornell box at 1920x1080 through the NEE+MIS wavefront integrator with 30
-spectral bands.  One step = one batch of `--spp-per-step` samples per pixel (default 4, i.e. 8.3 M
+spectral bands.  One step = one batch of `--spp-per-step` samples per pixel (default 64, i.e. 133 M
 camera samples, the batch the wavefront queues are sized for); K steps are timed after W warm-up
 steps; value = samples per pixel per second over all GPUs.  With N>1 every rank renders its own
 sample indices of the same image (weak scaling: K steps per rank) into its own film, and the films
@@ -193,11 +193,11 @@ def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--cpu-spp", type=int, default=256)
     ap.add_argument("--soup-tris", type=int, default=1000000)
     ap.add_argument("--soup-sigma", type=float, default=0.004)
@@ -314,7 +314,7 @@ def main():
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "k_trace (closest hit)", "kernel_ms_avg": avg_ms, "launches": k["launches"],
                 "rays": k["items"], "kernel_ms_total": k["ms"], "mrays_per_s_in_kernel": k["items"] / max(k["ms"], 1e-9) / 1e3}
-        default_workload = (nx, ny, spp, args.algorithm) == (1920, 1080, 16, "mis")
+        default_workload = (nx, ny, spp, args.algorithm) == (1920, 1080, 64, "mis")
         tr, tr_file = recorded_traffic("r*_bench_traffic.json", "k_trace<true, false>")
         if tr is not None and default_workload:
             roof["traffic"] = tr["bytes_per_launch"]

@@ -235,7 +235,10 @@ int rt_render_begin(rt_context *ctx, int nx, int ny, int ns, int spectral_sample
  * (camera ray, integrator, film weight, Spectrum::add of rad/ns).  Work is queued on the context's stream.
  * A pass may leave the last few of its paths (the deep, nearly empty bounces) for the next pass to carry along;
  * rt_render_sync, the downloads, rt_get_stats and rt_profile_stop finish them first, so whatever those calls
- * return accounts for every sample of every pass.  Read the buffer of rt_film_device_ptr after rt_render_sync. */
+ * return accounts for every sample of every pass.  Read the buffer of rt_film_device_ptr after rt_render_sync.
+ * A pass is rendered in batches of up to 2^27 paths (64 samples per pixel at 1920x1080), and the wavefront queues take about 380
+ * bytes per path of the largest batch so far (51 GB for a full one); a pass of fewer samples allocates proportionally less, and the
+ * environment variable MI355RT_BATCH_LOG2 (20..28, read by rt_render_begin) caps the batch for hosts that must leave HBM to others. */
 int rt_render_pass(rt_context *ctx, int first_sample, int n_samples);
 /* finishes pending paths and waits for the context's stream */
 int rt_render_sync(rt_context *ctx);

@@ -108,6 +108,13 @@ constexpr int kMaxBounces = 62; // counter slots per batch; a longer path wraps 
 #ifndef BDPT_BATCH_LOG2
 #define BDPT_BATCH_LOG2 25
 #endif
+// Paths per batch of the unidirectional integrators: a batch pays the launches of its late, nearly empty bounces once, so large
+// batches are cheaper per sample (1080p NEE+MIS: 2^25 paths 3660 spp/s, 2^26 3950, 2^27 4100, 2^28 4210) and queue memory grows
+// with them (about 380 bytes per path: 51 GB at 2^27, allocated only as far as a pass needs it).  The environment variable
+// MI355RT_BATCH_LOG2 (20..28), read by rt_render_begin, overrides the default.
+#ifndef PATH_BATCH_LOG2
+#define PATH_BATCH_LOG2 27
+#endif
 #ifndef SHADE_MIN_BLOCKS
 #define SHADE_MIN_BLOCKS 1
 #endif
@@ -129,6 +136,7 @@ struct Impl {
 	float4 *light_box = nullptr;
 	bool cull_connections = true;
 	int cull_mask = 7;
+	int batch_log2 = PATH_BATCH_LOG2;
 	float4 scene_lo = {0, 0, 0, 0}, scene_hi = {0, 0, 0, 0}; // bounding box of all vertices, rounded outwards (scene_lo.w: largest |coordinate|)
 	DevBand *bands = nullptr;
 	uint32_t n_lights = 0, n_bands = 0;
@@ -1445,6 +1453,8 @@ hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, i
 		im.cull_connections = !(all && all[0] == '1');
 		const char *m = std::getenv("MI355RT_CULL_MASK"); // diagnostic: bit 0 camera rays, bit 1 dead paths, bit 2 hopeless connections
 		im.cull_mask = m ? std::atoi(m) : 7;
+		const char *b = std::getenv("MI355RT_BATCH_LOG2");
+		im.batch_log2 = b ? std::min(28, std::max(20, std::atoi(b))) : PATH_BATCH_LOG2;
 	}
 	{
 		std::vector<uint32_t> live;
@@ -1798,11 +1808,11 @@ hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample
 {
 	Impl &im = *impl_of(rs);
 	const uint64_t npix = (uint64_t)rs.nx * rs.ny;
-	// samples per batch: large batches amortise the nearly empty late bounces; queue memory is about 380 bytes per path (<= 2^25 paths, 12.7 GB)
+	// samples per batch: large batches amortise the nearly empty late bounces (see PATH_BATCH_LOG2)
 	if (rs.algorithm == RT_ALG_MIS_BDPT) return hipSuccess; // MISBDPT returns 0 for every sample (renderer.cpp:775-778): the film stays empty
 	const bool bdpt = rs.algorithm == RT_ALG_NAIVE_BDPT;
 	// NaiveBDPT keeps 16 subpath vertices per sample (832 bytes with the sample record): 2^25 samples per batch (28 GB, plus about 14 GB of connection queues on the Cornell box): late bounces hold few walkers, and a small batch pays their launches for few samples (2^22: 454 spp/s, 2^24: 570, 2^25: 591 at 1080p)
-	uint64_t per_batch = std::max<uint64_t>(1, (1ull << (bdpt ? BDPT_BATCH_LOG2 : 25)) / std::max<uint64_t>(npix, 1));
+	uint64_t per_batch = std::max<uint64_t>(1, (1ull << (bdpt ? BDPT_BATCH_LOG2 : im.batch_log2)) / std::max<uint64_t>(npix, 1));
 	if (npix * per_batch >= (1ull << 31)) per_batch = 1;
 	if (npix >= (1ull << 31)) { err = "image too large for 32-bit path indices"; return hipErrorInvalidValue; }
 	const uint64_t batch_paths = npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1));
