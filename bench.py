@@ -35,16 +35,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # bytes/s
 
 
-def recorded_traffic(pattern, kernel):
-    """HBM-side bytes per launch of `kernel` from the newest committed PMC summary matching `pattern`
+# the closest-hit kernel's instantiations (stack in LDS or in scratch; reference triangle test) as rocprofv3 names them
+CLOSEST_KERNELS = ("k_trace<true, false, false>", "k_trace<false, false, false>")
+
+
+def recorded_traffic(pattern, kernels):
+    """HBM-side bytes per launch of the first of `kernels` found in the newest committed PMC summary matching `pattern`
     (tools/profile.sh + tools/traffic_from_profile.py on this same command); None when there is none"""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
         return None, None
     rec = json.load(open(files[-1]))
-    k = rec["kernels"].get(kernel)
-    return (k, os.path.relpath(files[-1], ROOT)) if k else (None, None)
+    for name in kernels:
+        k = rec["kernels"].get(name)
+        if k and k.get("dispatches"):
+            return k, os.path.relpath(files[-1], ROOT)
+    return None, None
 
 
 def recorded_counters(pattern, kernel):
@@ -175,9 +182,7 @@ def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=
         res["algorithmic_rate_gbs"] = res["mrays_per_s"] * 1e6 * res["algorithmic_bytes_per_ray"] / 1e9
         res["algorithmic_note"] = ("48 B + 128 B per node fetched + 128 B per triangle record tested, counted by the oracle's walk of the kernel's own tree; "
                                    "part of it is served by the L2, so this rate can exceed what HBM delivers: the traffic figures below are the measured ones")
-    tr, tr_file = recorded_traffic("r*_%s_traffic.json" % tag, "k_trace<false, false>")
-    if tr is None:
-        tr, tr_file = recorded_traffic("r*_%s_traffic.json" % tag, "k_trace<true, false>")
+    tr, tr_file = recorded_traffic("r*_%s_traffic.json" % tag, CLOSEST_KERNELS)
     if tr is not None and tr.get("rays_per_launch", m) == m:
         # what bounds this kernel: the rate at which the memory side of the L2 serves random 128-byte lines
         # (tools/calib/random_lines.hip: 53 G lines/s from HBM, 57 G lines/s from the Infinity Cache)
@@ -315,7 +320,7 @@ def main():
                 "kernel": "k_trace (closest hit)", "kernel_ms_avg": avg_ms, "launches": k["launches"],
                 "rays": k["items"], "kernel_ms_total": k["ms"], "mrays_per_s_in_kernel": k["items"] / max(k["ms"], 1e-9) / 1e3}
         default_workload = (nx, ny, spp, args.algorithm) == (1920, 1080, 64, "mis")
-        tr, tr_file = recorded_traffic("r*_bench_traffic.json", "k_trace<true, false>")
+        tr, tr_file = recorded_traffic("r*_bench_traffic.json", CLOSEST_KERNELS)
         if tr is not None and default_workload:
             roof["traffic"] = tr["bytes_per_launch"]
             roof["achieved"] = tr["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
@@ -323,7 +328,7 @@ def main():
             roof["traffic_note"] = ("bytes per launch on the memory side of the L2 (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes over "
                                     "this command, recorded in %s) over the launch duration measured in this run: the tree and the triangles of "
                                     "this scene stay in the caches, only rays and hits reach HBM" % tr_file)
-            lim = recorded_counters("r*_bench_traffic.json", "k_trace<true, false>")
+            lim = recorded_counters("r*_bench_traffic.json", CLOSEST_KERNELS)
             if lim is not None:
                 roof["limiter"] = dict(lim, what="vector instruction issue, not memory (the scene is cache resident): valu_busy is the share of SIMD time spent "
                                                   "issuing vector instructions, valu_lane_utilization the share of their lanes that did work")

@@ -424,13 +424,19 @@ uint64_t orc_rng_seed(uint64_t seed, uint64_t pixel, uint64_t sample)
 {
 	return mix64(mix64(seed + 0x9E3779B97F4A7C15ULL * (sample + 1)) ^ (0xD1B54A32D192ED03ULL * (pixel + 1)));
 }
+/* One draw: PCG-XSH-RR 64/32 (O'Neill 2014) -- a 64-bit linear congruential step, output = the old state's high bits xor-shifted
+ * and rotated by its top five bits.  Every (pixel, sample) starts at its own point of the sequence (orc_rng_seed, two splitmix64
+ * rounds).  One 64-bit multiplication per draw, where a splitmix64 stream needs two: the device's generate kernel is bound by its
+ * vector instruction rate, and 64-bit multiplications are its most expensive instructions. */
 uint64_t orc_rng_next(uint64_t *state)
 {
-	*state += 0x9E3779B97F4A7C15ULL;
-	return mix64(*state);
+	const uint64_t old = *state;
+	*state = old * 6364136223846793005ULL + 1442695040888963407ULL;
+	const uint32_t xorshifted = (uint32_t)(((old >> 18) ^ old) >> 27), rot = (uint32_t)(old >> 59);
+	return (uint64_t)((xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u)));
 }
-double orc_rng_f64(uint64_t *state) { return (double)(orc_rng_next(state) >> 11) * (1.0 / 9007199254740992.0); }
-static inline uint32_t rng_below(uint64_t *state, uint32_t n) { return (uint32_t)((orc_rng_next(state) >> 32) % n); }
+double orc_rng_f64(uint64_t *state) { return (double)orc_rng_next(state) * (1.0 / 4294967296.0); }
+static inline uint32_t rng_below(uint64_t *state, uint32_t n) { return (uint32_t)(orc_rng_next(state) % n); }
 
 /* ======================================================================================= */
 /* Camera (camera.h:101-209)                                                                */

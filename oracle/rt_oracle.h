@@ -78,7 +78,7 @@ void orc_camera_get_ray(const orc_camera *c, double u, double v, double waveleng
 /* ---------------- counter-based random stream shared with the device code ---------------- */
 uint64_t orc_rng_seed(uint64_t seed, uint64_t pixel, uint64_t sample);
 uint64_t orc_rng_next(uint64_t *state);
-double   orc_rng_f64(uint64_t *state); /* (next >> 11) * 2^-53 */
+double   orc_rng_f64(uint64_t *state); /* next * 2^-32: 32-bit draws (PCG-XSH-RR 64/32) */
 
 /* ---------------- scene ---------------- */
 typedef struct orc_scene orc_scene;

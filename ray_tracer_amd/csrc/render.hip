@@ -193,7 +193,7 @@ __device__ __forceinline__ float len(f3 a) { return sqrtf(dot(a, a)); }
 __device__ __forceinline__ f3 unit(f3 a) { float l = len(a); return F3(a.x / l, a.y / l, a.z / l); }
 __device__ __forceinline__ f3 ld3(const float *p) { return F3(p[0], p[1], p[2]); }
 
-// the random stream shared with the CPU checker: splitmix64 steps from a per-(pixel, sample) seed
+// the random stream shared with the CPU checker: a per-(pixel, sample) seed from two splitmix64 rounds, then PCG draws
 __device__ __forceinline__ uint64_t mix64(uint64_t z)
 {
 	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -204,14 +204,19 @@ __device__ __forceinline__ uint64_t rng_seed(uint64_t seed, uint64_t pixel, uint
 {
 	return mix64(mix64(seed + 0x9E3779B97F4A7C15ULL * (sample + 1)) ^ (0xD1B54A32D192ED03ULL * (pixel + 1)));
 }
-__device__ __forceinline__ uint64_t rng_next(uint64_t &s)
+// one draw: PCG-XSH-RR 64/32 -- a 64-bit linear congruential step and a 32-bit output permuted from the old state.  One 64-bit
+// multiplication per draw (four quarter-rate 32-bit multiplies) where splitmix64 per draw needs two: the generate kernel runs at
+// the vector instruction rate, and these multiplies are its most expensive instructions
+__device__ __forceinline__ uint32_t rng_next(uint64_t &s)
 {
-	s += 0x9E3779B97F4A7C15ULL;
-	return mix64(s);
+	const uint64_t old = s;
+	s = old * 6364136223846793005ULL + 1442695040888963407ULL;
+	const uint32_t xorshifted = (uint32_t)(((old >> 18) ^ old) >> 27), rot = (uint32_t)(old >> 59);
+	return __builtin_rotateright32(xorshifted, rot);
 }
-// top 24 bits: the truncation of the checker's 53-bit uniform, so threshold decisions agree
-__device__ __forceinline__ float rng_f32(uint64_t &s) { return (float)(rng_next(s) >> 40) * (1.0f / 16777216.0f); }
-__device__ __forceinline__ uint32_t rng_below(uint64_t &s, uint32_t n) { return (uint32_t)((rng_next(s) >> 32) % n); }
+// top 24 bits: the truncation of the checker's 32-bit uniform, so threshold decisions agree
+__device__ __forceinline__ float rng_f32(uint64_t &s) { return (float)(rng_next(s) >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ uint32_t rng_below(uint64_t &s, uint32_t n) { return rng_next(s) % n; }
 
 struct Onb { f3 u, v, w; };
 __device__ __forceinline__ Onb onb_from_w(f3 n) // onb.cpp:31-42
