@@ -51,6 +51,29 @@ struct DevCamera {
 	float half_aperture, weight_scale; // weight_scale = film_sensitivity / (d^2 p_image p_lens)
 };
 
+// n / d and n % d for a divisor fixed at launch time without a division instruction (Granlund and Montgomery's multiply-and-shift,
+// branch-free form): t = mulhi(mul, n), q = (t + ((n - t) >> s1)) >> s2, exact for every 32-bit n and every d >= 1.
+// (A 32-bit division by a run-time value costs about 25 vector instructions; the generate kernel, which runs at the vector
+// instruction rate, made three per sample.)
+struct FastDiv { uint32_t d, mul, s1, s2; };
+inline FastDiv fast_div(uint32_t d)
+{
+	uint32_t l = 0;
+	while (l < 32 && (1ull << l) < d) l++;
+	FastDiv f;
+	f.d = d;
+	f.mul = (uint32_t)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+	f.s1 = l < 1 ? l : 1;
+	f.s2 = l > 1 ? l - 1 : 0;
+	return f;
+}
+__device__ __forceinline__ uint32_t operator/(uint32_t n, const FastDiv &f)
+{
+	const uint32_t t = __umulhi(f.mul, n);
+	return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+__device__ __forceinline__ uint32_t operator%(uint32_t n, const FastDiv &f) { return n - (n / f) * f.d; }
+
 struct DeviceShade {
 	const float4 *tri_shade;        // 6 float4 per fan triangle: v0 v1 v2 n0 n1 n2 face_normal area2
 	const uint32_t *tri_face, *face_object, *face_tri_begin;
@@ -62,6 +85,7 @@ struct DeviceShade {
 	const float4 *light_box;        // per light: (lo.xyz, largest |coordinate|), (hi.xyz, unused): bounding box of the polygon
 	const DevBand *bands;
 	uint32_t n_lights, n_bands;
+	FastDiv by_lights;              // division by n_lights
 	const float *tri_uv;            // 9 floats per fan triangle: vt of its three corners (null: the mesh has none)
 	const uint2 *g_code;            // per-hit material programs: (op, arg) pairs
 	const float *g_spectra, *g_vectors, *g_scalars;
@@ -216,7 +240,7 @@ __device__ __forceinline__ uint32_t rng_next(uint64_t &s)
 }
 // top 24 bits: the truncation of the checker's 32-bit uniform, so threshold decisions agree
 __device__ __forceinline__ float rng_f32(uint64_t &s) { return (float)(rng_next(s) >> 8) * (1.0f / 16777216.0f); }
-__device__ __forceinline__ uint32_t rng_below(uint64_t &s, uint32_t n) { return rng_next(s) % n; }
+__device__ __forceinline__ uint32_t rng_below(uint64_t &s, const FastDiv &n) { return rng_next(s) % n; }
 
 struct Onb { f3 u, v, w; };
 __device__ __forceinline__ Onb onb_from_w(f3 n) // onb.cpp:31-42
@@ -620,8 +644,8 @@ __device__ __forceinline__ bool ray_may_reach(float4 b0, float4 b1, f3 o, f3 d)
 // alpha (beta), the pending factor alpha_ (weight), the sample slot (pixel)
 // one camera sample: the ray and the path state it starts with
 template <bool BDPT>
-__device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBand *__restrict__ bands, uint32_t n_bands, int nx, int ny, int ns,
-                                              int first_sample, int n_samples, uint64_t seed, float tmin, uint64_t idx, BdptSample *__restrict__ samples,
+__device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBand *__restrict__ bands, FastDiv n_bands, int nx, FastDiv ny, int ns,
+                                              int first_sample, FastDiv n_samples, uint64_t seed, float tmin, uint64_t idx, BdptSample *__restrict__ samples,
                                               rt_ray &r, PathState &st, const uint32_t *__restrict__ live = nullptr)
 {
 	// a batch holds fewer than 2^31 samples (render_pass): 32-bit divisions, a fraction of the cost of 64-bit ones
@@ -629,13 +653,13 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBan
 	// neighbouring film pixels instead of 64 different ones (scattered float atomics cost one memory request per 64-byte
 	// segment touched), and its camera rays start out coherent.
 	const uint32_t idx32 = (uint32_t)idx;
-	const uint32_t slot = idx32 / (uint32_t)n_samples, sample_off = idx32 - slot * (uint32_t)n_samples;
+	const uint32_t slot = idx32 / n_samples, sample_off = idx32 - slot * n_samples.d;
 	const uint32_t pixel = live ? live[slot] : slot; // only the pixels that can see the scene are generated at all
 	const int sample = first_sample + (int)sample_off;
-	const int i = (int)(pixel / (uint32_t)ny), j = (int)(pixel - (uint32_t)i * (uint32_t)ny);
+	const int i = (int)(pixel / ny), j = (int)(pixel - (uint32_t)i * ny.d);
 	uint64_t rng = rng_seed(seed, pixel, (uint64_t)sample);
 	const float u = ((float)i + rng_f32(rng)) / (float)nx;
-	const float v = ((float)j + rng_f32(rng)) / (float)ny;
+	const float v = ((float)j + rng_f32(rng)) / (float)ny.d;
 	const uint32_t k = rng_below(rng, n_bands);
 	const DevBand bd = bands[k];
 	float l0, l1;
@@ -673,8 +697,8 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBan
 
 // rays and state point at the first free queue slot (paths carried over from the previous batch sit in front of it)
 template <bool BDPT>
-__global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBand *__restrict__ bands, uint32_t n_bands,
-                                                     int nx, int ny, int ns, int first_sample, int n_samples, uint64_t n_paths,
+__global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBand *__restrict__ bands, FastDiv n_bands,
+                                                     int nx, FastDiv ny, int ns, int first_sample, FastDiv n_samples, uint64_t n_paths,
                                                      uint64_t seed, float tmin, rt_ray *__restrict__ rays,
                                                      PathState *__restrict__ state, BdptSample *__restrict__ samples)
 {
@@ -701,8 +725,8 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevCamera cam, const DevBan
 #endif
 constexpr int kGenBlock = GEN_BLOCK, kGenPer = GEN_PER;
 template <bool BDPT>
-__global__ void __launch_bounds__(kGenBlock) k_generate_cull(DevCamera cam, const DevBand *__restrict__ bands, uint32_t n_bands,
-                                                             int nx, int ny, int ns, int first_sample, int n_samples, uint64_t n_paths,
+__global__ void __launch_bounds__(kGenBlock) k_generate_cull(DevCamera cam, const DevBand *__restrict__ bands, FastDiv n_bands,
+                                                             int nx, FastDiv ny, int ns, int first_sample, FastDiv n_samples, uint64_t n_paths,
                                                              uint64_t seed, float tmin, rt_ray *__restrict__ rays,
                                                              PathState *__restrict__ state, BdptSample *__restrict__ samples, float4 box_lo,
                                                              float4 box_hi, unsigned long long *__restrict__ tails, const uint32_t *__restrict__ live)
@@ -857,7 +881,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 				const Onb uvw = onb_from_w(nrm);
 				const f3 vo = w2l(uvw, neg(d));
 				if (ALG != RT_ALG_NAIVE) {
-					const uint32_t sel = rng_below(st.rng, sh.n_lights);
+					const uint32_t sel = rng_below(st.rng, sh.by_lights);
 					const uint32_t lf = sh.light_faces[sel];
 					// GetRandomPointOnPolygon (object.cpp:340-372)
 					const float rr = rng_f32(st.rng);
@@ -1147,6 +1171,7 @@ DeviceShade make_shade(const Impl &im)
 	sh.cull_connections = im.cull_connections ? im.cull_mask : 0;
 	sh.bands = im.bands;
 	sh.n_lights = im.n_lights;
+	sh.by_lights = fast_div(std::max(im.n_lights, 1u));
 	sh.n_bands = im.n_bands;
 	sh.tri_uv = im.tri_uv;
 	sh.g_code = im.g_code;
@@ -1534,14 +1559,14 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 			prof.begin(Profiler::GENERATE, n_paths, stream);
 			if (cull_camera) {
 				const unsigned cull_blocks = (unsigned)((n_paths + kGenBlock * kGenPer - 1) / (kGenBlock * kGenPer));
-				hipLaunchKernelGGL(k_generate_cull<false>, dim3(cull_blocks), dim3(kGenBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns,
-				                   first_sample, n_samples, n_paths, rs.seed, tmin, im.rays[cur], im.state[cur], (BdptSample *)nullptr, im.scene_lo, im.scene_hi,
+				hipLaunchKernelGGL(k_generate_cull<false>, dim3(cull_blocks), dim3(kGenBlock), 0, stream, im.cam, im.bands, fast_div(im.n_bands), rs.nx, fast_div((uint32_t)rs.ny), rs.ns,
+				                   first_sample, fast_div((uint32_t)n_samples), n_paths, rs.seed, tmin, im.rays[cur], im.state[cur], (BdptSample *)nullptr, im.scene_lo, im.scene_hi,
 				                   &im.counters[0].tails, im.live_pixels);
 				// the queue length is what the kernel left in the counter; the host keeps its upper bound
 				HIP_TRY(hipMemcpyAsync(&im.h_counters[0], &im.counters[0], sizeof(Counters), hipMemcpyDeviceToHost, stream));
 			} else {
-				hipLaunchKernelGGL(k_generate<false>, dim3(blocks), dim3(kBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns,
-				                   first_sample, n_samples, n_paths, rs.seed, tmin, im.rays[cur] + carried, im.state[cur] + carried, (BdptSample *)nullptr);
+				hipLaunchKernelGGL(k_generate<false>, dim3(blocks), dim3(kBlock), 0, stream, im.cam, im.bands, fast_div(im.n_bands), rs.nx, fast_div((uint32_t)rs.ny), rs.ns,
+				                   first_sample, fast_div((uint32_t)n_samples), n_paths, rs.seed, tmin, im.rays[cur] + carried, im.state[cur] + carried, (BdptSample *)nullptr);
 			}
 			prof.end(stream);
 			HIP_TRY(hipGetLastError());
@@ -1679,16 +1704,16 @@ static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &ge
 	if (im.cull_connections) {
 		HIP_TRY(hipMemsetAsync(im.counters, 0, sizeof(Counters), stream));
 		const unsigned cull_blocks = (unsigned)((n_generated + kGenBlock * kGenPer - 1) / (kGenBlock * kGenPer));
-		hipLaunchKernelGGL(k_generate_cull<true>, dim3(cull_blocks), dim3(kGenBlock), 0, stream, im.cam, im.bands, im.n_bands, rs.nx, rs.ny, rs.ns,
-		                   first_sample, n_samples, n_generated, rs.seed, 0.001f, im.rays[0], im.state[0], samples, im.scene_lo, im.scene_hi, &im.counters[0].tails, im.live_pixels);
+		hipLaunchKernelGGL(k_generate_cull<true>, dim3(cull_blocks), dim3(kGenBlock), 0, stream, im.cam, im.bands, fast_div(im.n_bands), rs.nx, fast_div((uint32_t)rs.ny), rs.ns,
+		                   first_sample, fast_div((uint32_t)n_samples), n_generated, rs.seed, 0.001f, im.rays[0], im.state[0], samples, im.scene_lo, im.scene_hi, &im.counters[0].tails, im.live_pixels);
 		prof.end(stream);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(&im.h_counters[0], &im.counters[0], sizeof(Counters), hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream)); // one wait per batch of up to 2^25 samples: everything below is sized by the count
 		n_paths = (uint32_t)im.h_counters[0].tails;
 	} else {
-		hipLaunchKernelGGL(k_generate<true>, dim3((unsigned)((n_generated + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands, im.n_bands,
-		                   rs.nx, rs.ny, rs.ns, first_sample, n_samples, n_generated, rs.seed, 0.001f, im.rays[0], im.state[0], samples);
+		hipLaunchKernelGGL(k_generate<true>, dim3((unsigned)((n_generated + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands, fast_div(im.n_bands),
+		                   rs.nx, fast_div((uint32_t)rs.ny), rs.ns, first_sample, fast_div((uint32_t)n_samples), n_generated, rs.seed, 0.001f, im.rays[0], im.state[0], samples);
 		prof.end(stream);
 		HIP_TRY(hipGetLastError());
 	}
