@@ -81,6 +81,8 @@ struct DeviceShade {
 	const uint32_t *tri_leaf;       // fan triangle -> leaf-order index (exact polygon test in NEE)
 	const DevMaterial *materials;
 	const uint32_t *light_faces;
+	const uint4 *light_rec;         // per light: polygon, its first fan triangle, its number of fan triangles, its area (float bits):
+	                                // what a light pick needs, in one read instead of a chain of three dependent ones
 	int cull_connections;           // 0: trace every connection ray (diagnostic, MI355RT_TRACE_ALL_CONNECTIONS=1)
 	const float4 *light_box;        // per light: (lo.xyz, largest |coordinate|), (hi.xyz, unused): bounding box of the polygon
 	const DevBand *bands;
@@ -157,6 +159,7 @@ struct Impl {
 	float *face_area = nullptr, *tri_cum = nullptr;
 	DevMaterial *materials = nullptr;
 	uint32_t *light_faces = nullptr;
+	uint4 *light_rec = nullptr;
 	float4 *light_box = nullptr;
 	bool cull_connections = true;
 	int cull_mask = 7;
@@ -882,18 +885,19 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 				const f3 vo = w2l(uvw, neg(d));
 				if (ALG != RT_ALG_NAIVE) {
 					const uint32_t sel = rng_below(st.rng, sh.by_lights);
-					const uint32_t lf = sh.light_faces[sel];
+					const uint4 lrec = sh.light_rec[sel];
+					const uint32_t lf = lrec.x;
 					// GetRandomPointOnPolygon (object.cpp:340-372)
 					const float rr = rng_f32(st.rng);
-					const uint32_t t0 = sh.face_tri_begin[lf], nt = sh.face_tri_begin[lf + 1] - t0;
+					const uint32_t t0 = lrec.y, nt = lrec.z;
 					uint32_t lt = t0 + nt - 1;
-					for (uint32_t ti = 0; ti < nt; ti++)
+					for (uint32_t ti = 0; ti + 1 < nt; ti++) // the last cumulative area is 1: a triangle light needs no table look-up at all
 						if (rr < sh.tri_cum[t0 + ti]) { lt = t0 + ti; break; }
 					const TriShade ltri = load_tri(sh.tri_shade, lt);
 					float x = rng_f32(st.rng), y = rng_f32(st.rng);
 					if (x + y >= 1.0f) { x = 1.0f - x; y = 1.0f - y; }
 					const f3 pl = ltri.v0 + x * (ltri.v1 - ltri.v0) + y * (ltri.v2 - ltri.v0);
-					const float area = sh.face_area[lf];
+					const float area = __uint_as_float(lrec.w);
 					const f3 to_l = pl - p;
 					const float dist = len(to_l);
 					const f3 sd = F3(to_l.x / dist, to_l.y / dist, to_l.z / dist);
@@ -1167,6 +1171,7 @@ DeviceShade make_shade(const Impl &im)
 	sh.tri_leaf = im.tri_leaf;
 	sh.materials = im.materials;
 	sh.light_faces = im.light_faces;
+	sh.light_rec = im.light_rec;
 	sh.light_box = im.light_box;
 	sh.cull_connections = im.cull_connections ? im.cull_mask : 0;
 	sh.bands = im.bands;
@@ -1337,6 +1342,17 @@ hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const
 	free_graphs(im); // new records: programs have to be attached again
 	HIP_TRY(upload(im.light_faces, light_faces, stream));
 	im.n_lights = (uint32_t)light_faces.size();
+	{
+		std::vector<uint4> recs(light_faces.size());
+		for (size_t l = 0; l < light_faces.size(); l++) {
+			const uint32_t f = light_faces[l];
+			const float area = (float)host.polygon_area[f];
+			uint32_t bits;
+			std::memcpy(&bits, &area, sizeof(bits));
+			recs[l] = make_uint4(f, (uint32_t)host.tri_begin[f], (uint32_t)(host.tri_begin[f + 1] - host.tri_begin[f]), bits);
+		}
+		HIP_TRY(upload(im.light_rec, recs, stream));
+	}
 	// bounding boxes of the light polygons, rounded outwards to float (see ray_may_reach_box)
 	std::vector<float4> boxes(2 * light_faces.size());
 	for (size_t l = 0; l < light_faces.size(); l++) {
@@ -1959,6 +1975,7 @@ void render_free(RenderState &rs)
 		if (im.tri_cum) (void)hipFree(im.tri_cum);
 		if (im.materials) (void)hipFree(im.materials);
 		if (im.light_faces) (void)hipFree(im.light_faces);
+		if (im.light_rec) (void)hipFree(im.light_rec);
 		if (im.light_box) (void)hipFree(im.light_box);
 		if (im.bands) (void)hipFree(im.bands);
 		if (im.env) (void)hipFree(im.env);
