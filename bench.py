@@ -35,8 +35,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # bytes/s
 
 
-# the closest-hit kernel's instantiations (stack in LDS or in scratch; reference triangle test) as rocprofv3 names them
-CLOSEST_KERNELS = ("k_trace<true, false, false>", "k_trace<false, false, false>")
+# the closest-hit kernel's instantiations (stack in LDS or in scratch; reference triangle test; cache-resident scene or not) as
+# rocprofv3 names them; the three-parameter names are those of summaries recorded before the last parameter existed
+CLOSEST_KERNELS = ("k_trace<true, false, false, true>", "k_trace<true, false, false, false>", "k_trace<false, false, false, true>",
+                   "k_trace<false, false, false, false>", "k_trace<true, false, false>", "k_trace<false, false, false>")
 
 
 def recorded_traffic(pattern, kernels):
