@@ -81,8 +81,10 @@ struct DeviceShade {
 	const uint32_t *tri_leaf;       // fan triangle -> leaf-order index (exact polygon test in NEE)
 	const DevMaterial *materials;
 	const uint32_t *light_faces;
-	const uint4 *light_rec;         // per light: polygon, its first fan triangle, its number of fan triangles, its area (float bits):
-	                                // what a light pick needs, in one read instead of a chain of three dependent ones
+	const uint4 *light_rec;         // per light two uint4: (polygon, its first fan triangle, its number of fan triangles, its area as float
+	                                // bits) and (the cumulative area shares of its first three fan triangles as float bits, 0): what a
+	                                // light pick needs, in one read instead of a chain of dependent ones (polygons of more than four
+	                                // fan triangles go on in tri_cum)
 	int cull_connections;           // 0: trace every connection ray (diagnostic, MI355RT_TRACE_ALL_CONNECTIONS=1)
 	const float4 *light_box;        // per light: (lo.xyz, largest |coordinate|), (hi.xyz, unused): bounding box of the polygon
 	const DevBand *bands;
@@ -860,6 +862,36 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 		const rt_hit h = hits[idx];
 		const rt_ray r = rays[idx];
 		const uint32_t band = st.band_bounce & 0xFFFFu, bounce = st.band_bounce >> 16;
+		// The light pick and the point on the light need nothing but the path's random stream, and they are the first draws of a
+		// vertex (renderer.cpp:252-256 / 356-364): they are made here, on a copy of the stream that a surviving vertex adopts, so
+		// that their reads (light record -> that triangle's vertices) travel together with the reads that hang on the hit (triangle,
+		// material, band) instead of queueing up behind them: this kernel waits for dependent reads more than half of its time.
+		uint64_t rng_l = st.rng;
+		uint32_t lf = 0, lt = 0, sel = 0;
+		float l_area = 0.0f;
+		f3 pl = F3(0, 0, 0), l_fn = F3(0, 0, 0);
+		TriShade ltri{};
+		if (ALG != RT_ALG_NAIVE) {
+			sel = rng_below(rng_l, sh.by_lights);
+			const uint4 lrec = sh.light_rec[2 * sel], lcum = sh.light_rec[2 * sel + 1];
+			lf = lrec.x;
+			l_area = __uint_as_float(lrec.w);
+			// GetRandomPointOnPolygon (object.cpp:340-372)
+			const float rr = rng_f32(rng_l);
+			const uint32_t t0 = lrec.y, nt = lrec.z;
+			lt = t0 + nt - 1; // the last cumulative area is 1: a triangle light needs no look-up at all
+			if (nt > 1 && rr < __uint_as_float(lcum.x)) lt = t0;
+			else if (nt > 2 && rr < __uint_as_float(lcum.y)) lt = t0 + 1;
+			else if (nt > 3 && rr < __uint_as_float(lcum.z)) lt = t0 + 2;
+			else for (uint32_t ti = 3; ti + 1 < nt; ti++)
+				if (rr < sh.tri_cum[t0 + ti]) { lt = t0 + ti; break; }
+			ltri = load_tri(sh.tri_shade, lt);
+			float x = rng_f32(rng_l), y = rng_f32(rng_l);
+			if (x + y >= 1.0f) { x = 1.0f - x; y = 1.0f - y; }
+			pl = ltri.v0 + x * (ltri.v1 - ltri.v0) + y * (ltri.v2 - ltri.v0);
+			l_fn = ltri.fn;
+			if (!GRAPHS) asm volatile("" : : "v"(pl.x), "v"(pl.y), "v"(pl.z), "v"(l_fn.x), "v"(l_fn.y), "v"(l_fn.z)); // keeps the reads up here
+		}
 		const DevBand bd = sh.bands[band];
 		if (ALG == RT_ALG_NAIVE && h.prim == RT_MISS && sh.env != nullptr) // renderer.cpp:175-193
 			film_add(film, st.pixel, bd, st.beta * environment_radiance(sh, r, bd.get_bin) * st.weight);
@@ -884,20 +916,8 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 				const Onb uvw = onb_from_w(nrm);
 				const f3 vo = w2l(uvw, neg(d));
 				if (ALG != RT_ALG_NAIVE) {
-					const uint32_t sel = rng_below(st.rng, sh.by_lights);
-					const uint4 lrec = sh.light_rec[sel];
-					const uint32_t lf = lrec.x;
-					// GetRandomPointOnPolygon (object.cpp:340-372)
-					const float rr = rng_f32(st.rng);
-					const uint32_t t0 = lrec.y, nt = lrec.z;
-					uint32_t lt = t0 + nt - 1;
-					for (uint32_t ti = 0; ti + 1 < nt; ti++) // the last cumulative area is 1: a triangle light needs no table look-up at all
-						if (rr < sh.tri_cum[t0 + ti]) { lt = t0 + ti; break; }
-					const TriShade ltri = load_tri(sh.tri_shade, lt);
-					float x = rng_f32(st.rng), y = rng_f32(st.rng);
-					if (x + y >= 1.0f) { x = 1.0f - x; y = 1.0f - y; }
-					const f3 pl = ltri.v0 + x * (ltri.v1 - ltri.v0) + y * (ltri.v2 - ltri.v0);
-					const float area = __uint_as_float(lrec.w);
+					st.rng = rng_l; // the draws of the light pick above
+					const float area = l_area;
 					const f3 to_l = pl - p;
 					const float dist = len(to_l);
 					const f3 sd = F3(to_l.x / dist, to_l.y / dist, to_l.z / dist);
@@ -911,7 +931,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 					c0.pixel = st.pixel;
 					if (ALG == RT_ALG_NEE) { // renderer.cpp:258-286
 						cr0.tmax = dist - 0.0001f;
-						const float G = fabsf(dot(sd, ltri.fn) * dot(sd, nrm) / dot(to_l, to_l));
+						const float G = fabsf(dot(sd, l_fn) * dot(sd, nrm) / dot(to_l, to_l));
 						const DevMaterial &lm = sh.materials[sh.face_object[lf]]; // Emitted(shadow_ray, light_rec, light_rec.vt), :278-282
 						const float light = mat_emitted<GRAPHS>(sh, lm, (GRAPHS && lm.prog_len) ? hit_uv(sh, lt, ltri, pl) : F3(0, 0, 0), bd);
 						c0.c0 = bsdf * st.beta * light * G / lpa * st.weight;
@@ -1343,13 +1363,19 @@ hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const
 	HIP_TRY(upload(im.light_faces, light_faces, stream));
 	im.n_lights = (uint32_t)light_faces.size();
 	{
-		std::vector<uint4> recs(light_faces.size());
+		std::vector<uint4> recs(2 * light_faces.size());
 		for (size_t l = 0; l < light_faces.size(); l++) {
 			const uint32_t f = light_faces[l];
+			const uint64_t t0 = host.tri_begin[f], nt = host.tri_begin[f + 1] - t0;
 			const float area = (float)host.polygon_area[f];
-			uint32_t bits;
+			uint32_t bits, cum[3] = {0, 0, 0};
 			std::memcpy(&bits, &area, sizeof(bits));
-			recs[l] = make_uint4(f, (uint32_t)host.tri_begin[f], (uint32_t)(host.tri_begin[f + 1] - host.tri_begin[f]), bits);
+			for (uint64_t k = 0; k < 3 && k < nt; k++) {
+				const float c = (float)host.tri_cum[t0 + k]; // the same conversion as the device's tri_cum table
+				std::memcpy(&cum[k], &c, sizeof(float));
+			}
+			recs[2 * l] = make_uint4(f, (uint32_t)t0, (uint32_t)nt, bits);
+			recs[2 * l + 1] = make_uint4(cum[0], cum[1], cum[2], 0u);
 		}
 		HIP_TRY(upload(im.light_rec, recs, stream));
 	}
