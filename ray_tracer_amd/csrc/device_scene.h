@@ -27,6 +27,8 @@ struct DeviceGeom {
 	uint32_t n_tris;
 	uint32_t depth;
 	uint32_t watertight;         // 0: the reference's triangle test; 1: the watertight test (rt_set_triangle_test)
+	uint32_t surface_rays;       // 1: the rays are an integrator's (set by the render passes on their copy): they end on surfaces, so most
+	                             // node visits find a leaf and the kernel variant that always fetches a node's whole header pays
 };
 
 } // namespace mi355rt

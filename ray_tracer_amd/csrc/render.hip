@@ -1876,8 +1876,10 @@ static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &ge
 	return hipSuccess;
 }
 
-hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample, int n_samples, hipStream_t stream, std::string &err)
+hipError_t render_pass(RenderState &rs, const DeviceGeom &scene_geom, int first_sample, int n_samples, hipStream_t stream, std::string &err)
 {
+	DeviceGeom geom = scene_geom;
+	geom.surface_rays = 1; // see launch_trace in trace.hip
 	Impl &im = *impl_of(rs);
 	const uint64_t npix = (uint64_t)rs.nx * rs.ny;
 	// samples per batch: large batches amortise the nearly empty late bounces (see PATH_BATCH_LOG2)
@@ -1908,8 +1910,10 @@ hipError_t render_pass(RenderState &rs, const DeviceGeom &geom, int first_sample
 	return hipSuccess;
 }
 
-hipError_t render_flush(RenderState &rs, const DeviceGeom &geom, hipStream_t stream, std::string &err)
+hipError_t render_flush(RenderState &rs, const DeviceGeom &scene_geom, hipStream_t stream, std::string &err)
 {
+	DeviceGeom geom = scene_geom;
+	geom.surface_rays = 1;
 	if (!rs.impl || !rs.begun) return hipSuccess;
 	Impl &im = *impl_of(rs);
 	if (im.carry_count == 0) return hipSuccess;

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 #include "device_scene.h"
 #include "trace.h"
@@ -577,7 +578,14 @@ hipError_t launch_trace(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, r
 	if (g.depth > (uint32_t)kScratchStack) return hipErrorInvalidValue;
 	const TraceGrid tg = trace_grid(n);
 	const bool lds = g.depth <= (uint32_t)kLdsStack;
-	const bool resident = g.tri_stride == 7; // the packed record layout is what the builders choose for scenes that fit the caches
+	// Which variant: the one that fetches a node's whole header at once saves a round trip to the cache per node with a leaf hit and
+	// costs 12 bytes per lane and node otherwise.  It wins where most visits find a leaf and the tree is served by the caches (the
+	// Cornell box +7 %, a 870 k-triangle mesh in the box +4 %) and loses where rays wander through a soup that waits for memory (-10 %
+	// at 1M triangles: one visit in ten finds a leaf).  Chosen for scenes small enough to live in the caches (their builders pack the
+	// triangle records) and for an integrator's own rays.
+	bool resident = g.tri_stride == 7 || g.surface_rays != 0;
+	static const char *const force = std::getenv("MI355RT_TRACE_RESIDENT"); // experiments: 0 / 1 overrides the choice
+	if (force && (force[0] == '0' || force[0] == '1')) resident = force[0] == '1';
 #define TRACE_LAUNCH(L, W, R) hipLaunchKernelGGL((k_trace<L, ANY, W, R>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, d_any, d_n)
 #define TRACE_LAUNCH_R(L, W) do { if (resident) TRACE_LAUNCH(L, W, true); else TRACE_LAUNCH(L, W, false); } while (0)
 	if (g.watertight) { if (lds) TRACE_LAUNCH_R(true, true); else TRACE_LAUNCH_R(false, true); }
