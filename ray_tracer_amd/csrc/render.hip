@@ -133,9 +133,15 @@ constexpr int kMaxBounces = 62; // counter slots per batch; a longer path wraps 
 #ifndef SHADE_BLOCK
 #define SHADE_BLOCK 512
 #endif
-#ifndef BDPT_BATCH_LOG2
-#define BDPT_BATCH_LOG2 25
+// NaiveBDPT samples per batch, at most: 16 subpath vertices and a sample record (832 bytes), the path queues (380) and, on the
+// Cornell box, 4.6 connection slots (80 bytes each) per sample, about 1.6 KB.  Late bounces hold few walkers, and a small batch pays
+// their launches for few samples (1080p: 2^22 454 spp/s, 2^24 570, 2^25 591 with the first version of the stages; now 2^25 1061,
+// 2^26 1106, 2^27 1232): the batch is as large as fits in three quarters of the memory that is free when the first batch is set up
+// (2^27 on an otherwise empty 288 GB GPU); MI355RT_BDPT_BATCH_LOG2 (20..27) fixes it.
+#ifndef BDPT_BATCH_LOG2_MAX
+#define BDPT_BATCH_LOG2_MAX 27
 #endif
+constexpr uint64_t kBdptBytesPerSample = 1650;
 // Paths per batch of the unidirectional integrators: a batch pays the launches of its late, nearly empty bounces once, so large
 // batches are cheaper per sample (1080p NEE+MIS: 2^25 paths 3660 spp/s, 2^26 3950, 2^27 4100, 2^28 4210) and queue memory grows
 // with them (about 380 bytes per path: 51 GB at 2^27, allocated only as far as a pass needs it).  The environment variable
@@ -204,6 +210,7 @@ struct Impl {
 	uint32_t *bdpt_counts = nullptr, *bdpt_offsets = nullptr;
 	unsigned long long *bdpt_pairs = nullptr;
 	uint64_t bdpt_capacity = 0;
+	int bdpt_batch_log2 = 0; // 0: not chosen yet (see BDPT_BATCH_LOG2_MAX)
 	size_t bdpt_scan_bytes = 0;
 };
 
@@ -1751,7 +1758,7 @@ static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &ge
 		prof.end(stream);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(&im.h_counters[0], &im.counters[0], sizeof(Counters), hipMemcpyDeviceToHost, stream));
-		HIP_TRY(hipStreamSynchronize(stream)); // one wait per batch of up to 2^25 samples: everything below is sized by the count
+		HIP_TRY(hipStreamSynchronize(stream)); // one wait per batch of up to 2^27 samples: everything below is sized by the count
 		n_paths = (uint32_t)im.h_counters[0].tails;
 	} else {
 		hipLaunchKernelGGL(k_generate<true>, dim3((unsigned)((n_generated + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, im.cam, im.bands, fast_div(im.n_bands),
@@ -1853,7 +1860,9 @@ static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &ge
 			// the path queues are useless without their connection queues: drop them all, so that the next pass of any
 			// integrator allocates a complete set again instead of launching over null connection buffers
 			free_queues(im);
-			err = std::string("NaiveBDPT connection queues: ") + hipGetErrorString(ge);
+			if (im.bdpt_batch_log2 > 20) im.bdpt_batch_log2--; // this scene makes more connections per sample than the batch size allowed for
+			err = std::string("NaiveBDPT connection queues: ") + hipGetErrorString(ge) +
+			      " (this pass is lost: begin the render again; later passes use batches of half the size, see MI355RT_BDPT_BATCH_LOG2)";
 			return ge;
 		}
 		im.conn_capacity = want;
@@ -1885,8 +1894,20 @@ hipError_t render_pass(RenderState &rs, const DeviceGeom &scene_geom, int first_
 	// samples per batch: large batches amortise the nearly empty late bounces (see PATH_BATCH_LOG2)
 	if (rs.algorithm == RT_ALG_MIS_BDPT) return hipSuccess; // MISBDPT returns 0 for every sample (renderer.cpp:775-778): the film stays empty
 	const bool bdpt = rs.algorithm == RT_ALG_NAIVE_BDPT;
-	// NaiveBDPT keeps 16 subpath vertices per sample (832 bytes with the sample record): 2^25 samples per batch (28 GB, plus about 14 GB of connection queues on the Cornell box): late bounces hold few walkers, and a small batch pays their launches for few samples (2^22: 454 spp/s, 2^24: 570, 2^25: 591 at 1080p)
-	uint64_t per_batch = std::max<uint64_t>(1, (1ull << (bdpt ? BDPT_BATCH_LOG2 : im.batch_log2)) / std::max<uint64_t>(npix, 1));
+	if (bdpt && im.bdpt_batch_log2 == 0) {
+		const char *b = std::getenv("MI355RT_BDPT_BATCH_LOG2");
+		if (b) im.bdpt_batch_log2 = std::min(BDPT_BATCH_LOG2_MAX, std::max(20, std::atoi(b)));
+		else {
+			size_t free_b = 0, total_b = 0;
+			HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+			// what this context already holds for BDPT or for its queues is given back before a larger batch is set up, so it counts as free
+			const uint64_t usable = (uint64_t)free_b / 4 * 3;
+			int lg = BDPT_BATCH_LOG2_MAX;
+			while (lg > 20 && (kBdptBytesPerSample << lg) > usable) lg--;
+			im.bdpt_batch_log2 = lg;
+		}
+	}
+	uint64_t per_batch = std::max<uint64_t>(1, (1ull << (bdpt ? im.bdpt_batch_log2 : im.batch_log2)) / std::max<uint64_t>(npix, 1));
 	if (npix * per_batch >= (1ull << 31)) per_batch = 1;
 	if (npix >= (1ull << 31)) { err = "image too large for 32-bit path indices"; return hipErrorInvalidValue; }
 	const uint64_t batch_paths = npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1));
