@@ -82,12 +82,14 @@ struct DeviceShade {
 	const DevMaterial *materials;
 	const uint32_t *light_faces;
 	const uint4 *light_rec;         // per light two uint4: (polygon, its first fan triangle, its number of fan triangles, its area as float
-	                                // bits) and (the cumulative area shares of its first three fan triangles as float bits, 0): what a
+	                                // bits) and (the cumulative area shares of its first three fan triangles as float bits, its obj object): what a
 	                                // light pick needs, in one read instead of a chain of dependent ones (polygons of more than four
 	                                // fan triangles go on in tri_cum)
 	int cull_connections;           // 0: trace every connection ray (diagnostic, MI355RT_TRACE_ALL_CONNECTIONS=1)
 	const float4 *light_box;        // per light: (lo.xyz, largest |coordinate|), (hi.xyz, unused): bounding box of the polygon
 	const DevBand *bands;
+	const float *emit;              // [object * n_bands + band]: Emitted() of a light whose colour is a constant spectrum, integrated over the
+	                                // band (0 for other materials): one read where the material record costs a chain of them
 	uint32_t n_lights, n_bands;
 	FastDiv by_lights;              // division by n_lights
 	const float *tri_uv;            // 9 floats per fan triangle: vt of its three corners (null: the mesh has none)
@@ -209,6 +211,9 @@ struct Impl {
 	void *bdpt_samples = nullptr, *bdpt_verts = nullptr, *bdpt_scan_tmp = nullptr;
 	uint32_t *bdpt_counts = nullptr, *bdpt_offsets = nullptr;
 	unsigned long long *bdpt_pairs = nullptr;
+	float *emit = nullptr;   // see DeviceShade::emit; rebuilt before a pass whenever materials, programs or bands have changed
+	size_t emit_size = 0;
+	bool emit_dirty = true;
 	uint64_t bdpt_capacity = 0;
 	int bdpt_batch_log2 = 0; // 0: not chosen yet (see BDPT_BATCH_LOG2_MAX)
 	size_t bdpt_scan_bytes = 0;
@@ -395,6 +400,23 @@ __device__ __forceinline__ float mat_emitted(const DeviceShade &sh, const DevMat
 	if (bd.flags & 2) sum += eval_graph(sh, m.prog_begin, m.prog_len, uv, bd.max_i + 1) * bd.mod_max;
 	for (int i = bd.min_i; i <= bd.max_i; i++) sum += eval_graph(sh, m.prog_begin, m.prog_len, uv, i) * 10.0f;
 	return sum;
+}
+
+// the same through the per-(object, band) table where the light's colour does not depend on the hit
+template <bool GRAPHS>
+__device__ __forceinline__ float emitted_at(const DeviceShade &sh, uint32_t object, const DevMaterial &m, f3 uv, const DevBand &bd, uint32_t band)
+{
+	if (GRAPHS && m.prog_len) return mat_emitted<GRAPHS>(sh, m, uv, bd);
+	return sh.emit[(size_t)object * sh.n_bands + band];
+}
+
+__global__ void __launch_bounds__(256) k_emit_table(const DevMaterial *__restrict__ materials, uint32_t n_objects, const DevBand *__restrict__ bands,
+                                                    uint32_t n_bands, float *__restrict__ out)
+{
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_objects * n_bands) return;
+	const DevMaterial &m = materials[i / n_bands];
+	out[i] = m.type == RT_MAT_DIFFUSE_LIGHT ? spectrum_integrate(m.a, bands[i % n_bands]) : 0.0f; // mat_emitted without a program
 }
 
 // RT_MAT_GGX: the micro-normal density of GGXReflectionNode::SampleBSDF (materialnode.cpp:669-675) as a function of the cosine between
@@ -874,7 +896,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 		// that their reads (light record -> that triangle's vertices) travel together with the reads that hang on the hit (triangle,
 		// material, band) instead of queueing up behind them: this kernel waits for dependent reads more than half of its time.
 		uint64_t rng_l = st.rng;
-		uint32_t lf = 0, lt = 0, sel = 0;
+		uint32_t lf = 0, lt = 0, sel = 0, l_obj = 0;
 		float l_area = 0.0f;
 		f3 pl = F3(0, 0, 0), l_fn = F3(0, 0, 0);
 		TriShade ltri{};
@@ -882,6 +904,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 			sel = rng_below(rng_l, sh.by_lights);
 			const uint4 lrec = sh.light_rec[2 * sel], lcum = sh.light_rec[2 * sel + 1];
 			lf = lrec.x;
+			l_obj = lcum.w;
 			l_area = __uint_as_float(lrec.w);
 			// GetRandomPointOnPolygon (object.cpp:340-372)
 			const float rr = rng_f32(rng_l);
@@ -913,10 +936,10 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 			const float tmin = r.tmin;
 			bool alive = true;
 			if (ALG == RT_ALG_NAIVE) {
-				film_add(film, st.pixel, bd, st.beta * mat_emitted<GRAPHS>(sh, m, uv, bd) * st.weight); // renderer.cpp:197
+				film_add(film, st.pixel, bd, st.beta * emitted_at<GRAPHS>(sh, h.object, m, uv, bd, band) * st.weight); // renderer.cpp:197
 			} else if (m.light_flag) { // renderer.cpp:242-251 / 346-355
 				if (bounce != 0) alive = false;
-				else film_add(film, st.pixel, bd, mat_emitted<GRAPHS>(sh, m, uv, bd) * st.weight);
+				else film_add(film, st.pixel, bd, emitted_at<GRAPHS>(sh, h.object, m, uv, bd, band) * st.weight);
 			}
 			if (alive) {
 				SHADE_LAP(0);
@@ -939,8 +962,8 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 					if (ALG == RT_ALG_NEE) { // renderer.cpp:258-286
 						cr0.tmax = dist - 0.0001f;
 						const float G = fabsf(dot(sd, l_fn) * dot(sd, nrm) / dot(to_l, to_l));
-						const DevMaterial &lm = sh.materials[sh.face_object[lf]]; // Emitted(shadow_ray, light_rec, light_rec.vt), :278-282
-						const float light = mat_emitted<GRAPHS>(sh, lm, (GRAPHS && lm.prog_len) ? hit_uv(sh, lt, ltri, pl) : F3(0, 0, 0), bd);
+						const DevMaterial &lm = sh.materials[l_obj]; // Emitted(shadow_ray, light_rec, light_rec.vt), :278-282
+						const float light = emitted_at<GRAPHS>(sh, l_obj, lm, (GRAPHS && lm.prog_len) ? hit_uv(sh, lt, ltri, pl) : F3(0, 0, 0), bd, band);
 						c0.c0 = bsdf * st.beta * light * G / lpa * st.weight;
 						c0.c1 = dist;
 						c0.band_kind = band | (2u << 16);
@@ -1092,20 +1115,28 @@ __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh
 		continue;
 	}
 	const rt_hit h = conn_hits[idx];
+	// Both records come whole and at once (left alone the compiler reads the two words of the test below first and the rest behind
+	// it), and everything that hangs on them goes out as one batch: ray, triangle, band, emission, area.  A thread has one item in
+	// flight, so the kernel's rate is the number of resident threads over the length of this chain of dependent reads.
+	asm volatile("" : : "v"(c.c0), "v"(c.c1), "v"(c.nx), "v"(c.ny), "v"(c.nz), "v"(c.pixel), "v"(c.band_kind), "v"(h.t), "v"(h.tri), "v"(h.object));
 	if (h.prim == RT_MISS || h.prim != c.sel_face) continue; // renderer.cpp:373-376 / 419-421
 	const rt_ray r = conn_rays[idx];
+	const TriShade tri = load_tri(sh.tri_shade, h.tri);
+	const float l_face_area = sh.face_area[c.sel_face];
+	const DevMaterial &lm = sh.materials[h.object];
+	const bool programmed = GRAPHS && lm.prog_len;
+	float light = programmed ? 0.0f : sh.emit[(size_t)h.object * sh.n_bands + (c.band_kind & 0xFFFFu)];
+	asm volatile("" : : "v"(l_face_area), "v"(light), "v"(bd.min_i), "v"(bd.max_i));
 	const f3 o = F3(r.ox, r.oy, r.oz), d = F3(r.dx, r.dy, r.dz);
 	const f3 pl = o + h.t * d;
-	const TriShade tri = load_tri(sh.tri_shade, h.tri);
 	const f3 ln = shading_normal(tri, pl);
 	// GeometryTerm(light_rec, rec), renderer.cpp:784-789
 	const f3 v = o - pl;
 	const f3 dir = unit(v);
 	const f3 nrm = F3(c.nx, c.ny, c.nz);
 	const float G = fabsf(dot(dir, ln) * dot(dir, nrm) / dot(v, v));
-	const DevMaterial &lm = sh.materials[h.object];
-	const float light = mat_emitted<GRAPHS>(sh, lm, (GRAPHS && lm.prog_len) ? hit_uv(sh, h.tri, tri, pl) : F3(0, 0, 0), bd);
-	const float lpa = 1.0f / sh.face_area[c.sel_face] / (float)sh.n_lights;
+	if (programmed) light = mat_emitted<GRAPHS>(sh, lm, hit_uv(sh, h.tri, tri, pl), bd);
+	const float lpa = 1.0f / l_face_area / (float)sh.n_lights;
 	float add;
 	if (kind == 0) add = power_heuristic2(lpa, c.c1 * G) * (c.c0 * G) * light;      // renderer.cpp:390-399
 	else add = power_heuristic2(G * c.c1, lpa) * c.c0 * light;                      // renderer.cpp:422-429
@@ -1202,6 +1233,7 @@ DeviceShade make_shade(const Impl &im)
 	sh.light_box = im.light_box;
 	sh.cull_connections = im.cull_connections ? im.cull_mask : 0;
 	sh.bands = im.bands;
+	sh.emit = im.emit;
 	sh.n_lights = im.n_lights;
 	sh.by_lights = fast_div(std::max(im.n_lights, 1u));
 	sh.n_bands = im.n_bands;
@@ -1349,6 +1381,7 @@ hipError_t render_upload_material_graphs(RenderState &rs, const rt_material_grap
 	}
 	HIP_TRY(upload(im.materials, dm, stream));
 	im.host_materials = dm;
+	im.emit_dirty = true;
 	return hipSuccess;
 }
 
@@ -1366,6 +1399,7 @@ hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const
 	}
 	HIP_TRY(upload(im.materials, dm, stream));
 	im.host_materials = dm;
+	im.emit_dirty = true;
 	free_graphs(im); // new records: programs have to be attached again
 	HIP_TRY(upload(im.light_faces, light_faces, stream));
 	im.n_lights = (uint32_t)light_faces.size();
@@ -1382,7 +1416,7 @@ hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const
 				std::memcpy(&cum[k], &c, sizeof(float));
 			}
 			recs[2 * l] = make_uint4(f, (uint32_t)t0, (uint32_t)nt, bits);
-			recs[2 * l + 1] = make_uint4(cum[0], cum[1], cum[2], 0u);
+			recs[2 * l + 1] = make_uint4(cum[0], cum[1], cum[2], host.face_object[f]);
 		}
 		HIP_TRY(upload(im.light_rec, recs, stream));
 	}
@@ -1496,6 +1530,7 @@ hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, i
 	}
 	HIP_TRY(upload(im.bands, bands, stream));
 	im.n_bands = (uint32_t)spectral_samples;
+	im.emit_dirty = true;
 	DevCamera &dc = im.cam;
 	for (int c = 0; c < 3; c++) {
 		dc.origin[c] = (float)cam.origin[c];
@@ -1544,6 +1579,25 @@ hipError_t render_begin(RenderState &rs, const rt_camera &cam, int nx, int ny, i
 	}
 	rs.begun = true;
 	return hipStreamSynchronize(stream);
+}
+
+static hipError_t ensure_emit(Impl &im, hipStream_t stream, std::string &err)
+{
+	if (!im.emit_dirty) return hipSuccess;
+	const size_t n = im.host_materials.size() * (size_t)im.n_bands;
+	if (n > im.emit_size) {
+		if (im.emit) (void)hipFree(im.emit);
+		im.emit = nullptr;
+		im.emit_size = 0;
+		HIP_TRY(hipMalloc((void **)&im.emit, n * sizeof(float)));
+		im.emit_size = n;
+	}
+	if (n) {
+		hipLaunchKernelGGL(k_emit_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, im.materials, (uint32_t)im.host_materials.size(), im.bands, im.n_bands, im.emit);
+		HIP_TRY(hipGetLastError());
+	}
+	im.emit_dirty = false;
+	return hipSuccess;
 }
 
 static hipError_t ensure_queues(Impl &im, uint64_t cap, std::string &err)
@@ -1914,6 +1968,7 @@ hipError_t render_pass(RenderState &rs, const DeviceGeom &scene_geom, int first_
 	const uint64_t queue_paths = batch_paths + batch_paths / kCarryDivisor + 1; // room for the paths carried over from the batch before
 	if ((queue_paths > im.capacity || bdpt) && im.carry_count) HIP_TRY(render_flush(rs, geom, stream, err)); // growing frees the queues they sit in
 	HIP_TRY(ensure_queues(im, queue_paths, err));
+	HIP_TRY(ensure_emit(im, stream, err));
 	if (bdpt) HIP_TRY(ensure_bdpt(im, npix * std::min<uint64_t>(per_batch, (uint64_t)std::max(n_samples, 1)), stream, err));
 	int s = first_sample, end = first_sample + n_samples;
 	while (s < end) {
@@ -2027,6 +2082,7 @@ void render_free(RenderState &rs)
 		if (im.materials) (void)hipFree(im.materials);
 		if (im.light_faces) (void)hipFree(im.light_faces);
 		if (im.light_rec) (void)hipFree(im.light_rec);
+		if (im.emit) (void)hipFree(im.emit);
 		if (im.light_box) (void)hipFree(im.light_box);
 		if (im.bands) (void)hipFree(im.bands);
 		if (im.env) (void)hipFree(im.env);
