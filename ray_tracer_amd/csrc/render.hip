@@ -232,6 +232,9 @@ __device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y 
 __device__ __forceinline__ f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x); }
 __device__ __forceinline__ float len(f3 a) { return sqrtf(dot(a, a)); }
 __device__ __forceinline__ f3 unit(f3 a) { float l = len(a); return F3(a.x / l, a.y / l, a.z / l); }
+// The same with the instructions spelled out (v_rsq_f32 and three products): code that two kernels must execute identically cannot
+// leave the choice between a division and a shared reciprocal to the compiler, which decides anew wherever a function is inlined
+__device__ __forceinline__ f3 unit_rsq(f3 a) { const float r = __builtin_amdgcn_rsqf(dot(a, a)); return F3(a.x * r, a.y * r, a.z * r); }
 __device__ __forceinline__ f3 ld3(const float *p) { return F3(p[0], p[1], p[2]); }
 
 // the random stream shared with the CPU checker: a per-(pixel, sample) seed from two splitmix64 rounds, then PCG draws
@@ -295,6 +298,7 @@ enum { OP_SPEC = 0, OP_VEC, OP_UV, OP_ZERO_S, OP_ZERO_V, OP_IMAGE, OP_CHECKER, O
 
 __device__ float eval_graph(const DeviceShade &sh, uint32_t begin, uint32_t len, f3 uv, int bin)
 {
+#pragma clang fp reciprocal(off) // texel, checker and noise-cell indices are truncated quotients: divisions stay divisions here
 	f3 s0 = F3(0, 0, 0), s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0; // s0 is the top
 	for (uint32_t pc = begin; pc < begin + len; pc++) {
 		const uint2 c = sh.g_code[pc];
@@ -682,6 +686,7 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBan
                                               int first_sample, FastDiv n_samples, uint64_t seed, float tmin, uint64_t idx, BdptSample *__restrict__ samples,
                                               rt_ray &r, PathState &st, const uint32_t *__restrict__ live = nullptr)
 {
+#pragma clang fp reciprocal(off) // inlined into two kernels that must produce the same ray for the same sample: see unit_rsq
 	// a batch holds fewer than 2^31 samples (render_pass): 32-bit divisions, a fraction of the cost of 64-bit ones
 	// The samples of one pixel are neighbours in the queue (index = pixel * n_samples + sample): a wave then adds to a few
 	// neighbouring film pixels instead of 64 different ones (scattered float atomics cost one memory request per 64-byte
@@ -692,8 +697,8 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBan
 	const int sample = first_sample + (int)sample_off;
 	const int i = (int)(pixel / ny), j = (int)(pixel - (uint32_t)i * ny.d);
 	uint64_t rng = rng_seed(seed, pixel, (uint64_t)sample);
-	const float u = ((float)i + rng_f32(rng)) / (float)nx;
-	const float v = ((float)j + rng_f32(rng)) / (float)ny.d;
+	const float u = ((float)i + rng_f32(rng)) * __builtin_amdgcn_rcpf((float)nx);
+	const float v = ((float)j + rng_f32(rng)) * __builtin_amdgcn_rcpf((float)ny.d);
 	const uint32_t k = rng_below(rng, n_bands);
 	const DevBand bd = bands[k];
 	float l0, l1;
@@ -704,8 +709,8 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBan
 	const f3 hor = ld3(cam.horizontal), ver = ld3(cam.vertical);
 	const f3 isp = ld3(cam.llc_rel) + u * hor + v * ver;              // image_sensor_pos - origin
 	const f3 lens = (l0 * cam.half_aperture) * hor + (l1 * cam.half_aperture) * ver; // random_point_on_lens - origin
-	const float cos_theta = dot(unit(lens - isp), neg(ld3(cam.w)));
-	f3 dir = unit(bd.neg_a_over_d * isp - lens);                      // target - random_point_on_lens
+	const float cos_theta = dot(unit_rsq(lens - isp), neg(ld3(cam.w)));
+	f3 dir = unit_rsq(bd.neg_a_over_d * isp - lens);                  // target - random_point_on_lens
 	if (bd.a_positive == 0.0f) dir = neg(dir);
 	const f3 org = ld3(cam.origin) + lens;
 	r.ox = org.x; r.oy = org.y; r.oz = org.z; r.tmin = tmin;
@@ -822,6 +827,7 @@ __global__ void __launch_bounds__(kGenBlock) k_generate_cull(DevCamera cam, cons
 // theta = pi, an address past the texture (undefined there); here such an address reads the last texel.
 __device__ float environment_radiance(const DeviceShade &sh, const rt_ray &r, int get_bin)
 {
+#pragma clang fp reciprocal(off) // the texel index is a truncated quotient
 	const double ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
 	const double blen = sqrt(dx * dx + dy * dy + dz * dz), olen = sqrt(ox * ox + oy * oy + oz * oz);
 	const double a = blen * blen, b_prime = ox * dx + oy * dy + oz * dz, c = olen * olen - 100.0 * 100.0;
@@ -1045,6 +1051,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 __device__ bool face_hit_exact(const DeviceGeom &g, const DeviceShade &sh, uint32_t face, const rt_ray &r, double tmin, double tmax)
 {
 #pragma clang fp contract(off)
+#pragma clang fp reciprocal(off) // the same operations as the traversal kernel's test, bit for bit
 	const uint32_t t0 = sh.face_tri_begin[face], t1 = sh.face_tri_begin[face + 1];
 	const double ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
 	for (uint32_t t = t0; t < t1; t++) {
