@@ -10,6 +10,8 @@ The integrators themselves are restated from the reference source and anchored o
 figures recorded from a reference run (mean film value per pixel, rays per camera sample); their
 parity against the reference is otherwise unpinned.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -70,6 +72,27 @@ def test_spectral_sample_counts(ctx, cornell_dir):
 
 def test_quads_scene(ctx, cornell_dir):
     g, o, st, gs = render_both(ctx, cornell_dir, 32, 32, 4, 30, capi.ALG_MIS, seed=3, obj_name="cornell_box.obj")
+    compare(g, o, 0.05)
+
+
+@pytest.mark.parametrize("alg", [capi.ALG_NEE, capi.ALG_MIS, capi.ALG_NAIVE_BDPT])
+def test_polygon_light_of_six_fan_triangles(ctx, cornell_dir, tmp_path, alg):
+    """the light as a regular octagon (six fan triangles): the light pick walks the polygon's cumulative triangle areas, the first
+    three from the light's record and the rest from the per-triangle table (GetRandomPointOnPolygon, object.cpp:340-372)"""
+    import math
+    import shutil
+    for name in ("materials.json", "objmatmap.json"):
+        shutil.copy(os.path.join(cornell_dir, name), tmp_path / name)
+    lines = open(os.path.join(cornell_dir, "cornell_box.obj")).read().splitlines()
+    n_v = sum(1 for l in lines if l.startswith("v "))
+    at = lines.index("f 21/21/6 22/22/6 24/23/6 23/24/6")
+    lines[at] = "f " + " ".join("%d/21/6" % (n_v + 1 + k) for k in range(8))
+    for k in range(8):
+        th = math.radians(-22.5 + 45.0 * k)
+        lines.append("v %.6f 0.989296 %.6f" % (0.3 * math.cos(th), 0.3 * math.sin(th)))
+    (tmp_path / "octagon_light.obj").write_text("\n".join(lines) + "\n")
+    g, o, st, gs = render_both(ctx, str(tmp_path), 48, 48, 8, 30, alg, seed=11, obj_name="octagon_light.obj")
+    assert gs["n_lights"] == 1 and gs["n_triangles"] > gs["n_faces"]
     compare(g, o, 0.05)
 
 
