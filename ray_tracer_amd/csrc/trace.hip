@@ -23,11 +23,18 @@ namespace {
 #ifndef TRACE_LDS_STACK
 #define TRACE_LDS_STACK 16
 #endif
-#ifndef TRACE_REFILL_MIN
-#define TRACE_REFILL_MIN 8
+// idle lanes before a wave takes new rays / descending lanes below which the node phase ends; _R: scenes served by the caches, _S: others
+#ifndef TRACE_REFILL_MIN_R
+#define TRACE_REFILL_MIN_R 16
 #endif
-#ifndef TRACE_NODE_MIN_LANES
-#define TRACE_NODE_MIN_LANES 56
+#ifndef TRACE_REFILL_MIN_S
+#define TRACE_REFILL_MIN_S 8
+#endif
+#ifndef TRACE_NODE_MIN_LANES_R
+#define TRACE_NODE_MIN_LANES_R 62
+#endif
+#ifndef TRACE_NODE_MIN_LANES_S
+#define TRACE_NODE_MIN_LANES_S 48
 #endif
 #ifndef TRACE_COOP_LEAF
 #define TRACE_COOP_LEAF 1
@@ -138,7 +145,6 @@ __device__ __forceinline__ float next_up(float x) // smallest float > x for fini
 	return __int_as_float(i);
 }
 
-constexpr int kRefillMin = TRACE_REFILL_MIN; // idle lanes in a wave before it takes new rays
 constexpr float kBigInv = 1.2089258196146292e24f;   // 2^80: stands in for 1/d on an axis the ray does not move along
 constexpr float kTinyDir = 8.673617379884035e-19f;  // 2^-60, relative to the largest component
 
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 		const unsigned long long idle = __ballot(!active);
 		if (idle != 0 && chunk_lo + (next >> 6) * n_waves + wave_id < chunk_hi) {
 			const int nidle = __popcll(idle);
-			if (nidle >= kRefillMin) {
+			if (nidle >= (RESIDENT ? TRACE_REFILL_MIN_R : TRACE_REFILL_MIN_S)) {
 				const uint64_t seq = next + (uint64_t)__popcll(idle & lt);
 				const uint64_t chunk = chunk_lo + (seq >> 6) * n_waves + wave_id;
 				const uint64_t mine = chunk * 64 + (seq & 63);
@@ -367,7 +373,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					else { l1_base = h1.y; l1_m0 = h1.z; l1_m1 = h1.w; l1_hits = leaf_hits; }
 				}
 				if (__ballot(l0_hits == 0) == 0) break; // every lane still descending already holds triangles to test
-				if (TRACE_NODE_MIN_LANES > 0 && __popcll(__ballot(true)) < TRACE_NODE_MIN_LANES) break; // too few lanes left descending
+				if (__popcll(__ballot(true)) < (RESIDENT ? TRACE_NODE_MIN_LANES_R : TRACE_NODE_MIN_LANES_S)) break; // too few lanes left descending
 			}
 #if TRACE_COOP_LEAF
 		}
