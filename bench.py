@@ -310,7 +310,7 @@ def main():
     ok = bool(torch.isfinite(film).all().item())
 
     soup = soup10 = None
-    if not args.no_soup:
+    if not args.no_soup and world == 1:  # the single-GPU half of the metric: with N > 1 every rank would build and trace the same soups
         soup = soup_leg(args.soup_tris, args.soup_sigma, args.soup_rays, "soup1m", ctx, capi, synth, oracle, torch, rank, log, host_buffer=True)
         if not args.no_soup10m:
             soup10 = soup_leg(10_000_000, 0.002, args.soup_rays, "soup10m", ctx, capi, synth, oracle, torch, rank, log, reps=3)
