@@ -238,7 +238,9 @@ int rt_render_begin(rt_context *ctx, int nx, int ny, int ns, int spectral_sample
  * return accounts for every sample of every pass.  Read the buffer of rt_film_device_ptr after rt_render_sync.
  * A pass is rendered in batches of up to 2^27 paths (64 samples per pixel at 1920x1080), and the wavefront queues take about 380
  * bytes per path of the largest batch so far (51 GB for a full one); a pass of fewer samples allocates proportionally less, and the
- * environment variable MI355RT_BATCH_LOG2 (20..28, read by rt_render_begin) caps the batch for hosts that must leave HBM to others. */
+ * environment variable MI355RT_BATCH_LOG2 (20..28, read by rt_render_begin) caps the batch for hosts that must leave HBM to others.
+ * RT_ALG_NAIVE_BDPT also stores its subpath vertices (about 1.65 KB per sample in all): its batches are sized by the device memory
+ * that is free at its first pass (three quarters of it, at most 2^27 samples); MI355RT_BDPT_BATCH_LOG2 (20..27) fixes the size. */
 int rt_render_pass(rt_context *ctx, int first_sample, int n_samples);
 /* finishes pending paths and waits for the context's stream */
 int rt_render_sync(rt_context *ctx);
