@@ -1,7 +1,7 @@
 """Auxiliary measurement for the PLY row: the Cornell box with a scanned-model-sized PLY object (about 870 k triangles,
 procedural: no model files are available offline) of glass or metal inside it, 1920x1080, NEE+MIS.
 Prints one JSON line: load times (both parsers), BVH build, spp/s, closest-hit rate and roofline figures.
-usage: python tools/bench_ply_scene.py [--material glass|gold] [--spp 64] [--grid 660]"""
+usage: python tools/bench_ply_scene.py [--material glass|gold] [--spp 64] [--pass-spp 64] [--grid 660]"""
 import argparse
 import json
 import os
@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--material", default="glass")
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--grid", type=int, default=660)
+    ap.add_argument("--pass-spp", type=int, default=64, help="samples per pixel per render pass (one batch of the wavefront queues at 1080p)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-oracle", action="store_true")
@@ -61,7 +62,7 @@ def main():
                device_mb=st["device_bytes"] / 1e6)
     ctx.upload_materials(records)
     ctx.set_camera(cam)
-    spp, step = args.spp, 16
+    spp, step = args.spp, args.pass_spp
     ctx.render_begin(nx, ny, spp + step, 30, capi.ALG_MIS, 20261111)
     ctx.render_pass(0, step)  # warm-up
     ctx.render_sync()
