@@ -129,7 +129,8 @@ void Renderer::RenderImage(int nx, int ny, int ns, int spectral_samples, bool, b
 	int s = 0;
 	while (s < ns) {
 		if (stop_rendering) break; // once per pass, renderer.cpp:70
-		int b = std::min(std::max(1, samples_per_pass), ns - s);
+		const long long fill = std::max(1LL, (1LL << 27) / std::max(1LL, (long long)nx * ny));
+		int b = (int)std::min<long long>(samples_per_pass > 0 ? samples_per_pass : fill, ns - s);
 		if (rt_group_render_pass(gpu, s, b) != RT_OK) { // no sync here: the pass's last paths ride along with the next pass; the downloads finish them
 			last_error = rt_group_last_error(gpu);
 			std::fprintf(stderr, "%s\n", last_error.c_str());

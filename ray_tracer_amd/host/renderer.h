@@ -50,7 +50,10 @@ public:
 	float progress = 0.0;
 	// additions: the reference seeds its generator from random_device; a fixed seed makes runs repeatable
 	unsigned long long seed;
-	int samples_per_pass = 1;
+	// samples per pixel handed to the device at a time (the reference renders and previews one at a time, renderer.cpp:70-143).  0: as
+	// many as fill one batch of the device's queues (2^27 paths: 64 at 1920x1080) -- a pass is a batch, and a small batch pays the
+	// launches of its late, nearly empty bounces for few samples; stop_rendering, the preview and the progress are served per pass
+	int samples_per_pass = 0;
 	std::string last_error;
 
 private:

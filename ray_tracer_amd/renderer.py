@@ -25,7 +25,8 @@ class Renderer:
         self.n_lights = 0
         # the reference seeds mt19937 from random_device (renderer.cpp:14-15)
         self.seed = int(np.random.SeedSequence().entropy & 0xFFFFFFFFFFFFFFFF) if seed is None else int(seed)
-        self.samples_per_pass = 1
+        # samples per pixel handed to the device at a time; 0: as many as fill one batch of its queues (2^27 paths)
+        self.samples_per_pass = 0
 
     def Load(self, objfilename):  # renderer.cpp:18-22 (the parser's bool is ignored there as well)
         self.obj_loader = Obj()
@@ -90,7 +91,8 @@ class Renderer:
         while s < ns:
             if self.stop_rendering:  # checked once per pass, renderer.cpp:70
                 break
-            b = min(max(1, self.samples_per_pass), ns - s)
+            fill = max(1, (1 << 27) // max(1, nx * ny))
+            b = min(self.samples_per_pass if self.samples_per_pass > 0 else fill, ns - s)
             self.ctx.render_pass(s, b)  # no sync: the pass's last paths ride along with the next pass; the downloads finish them
             s += b
             if self.preview_img_flag or s == ns:
