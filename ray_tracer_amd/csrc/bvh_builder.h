@@ -25,6 +25,12 @@ struct BvhBuildOptions {
 	float cost_tri = 1.5f;  // SAH: one triangle test
 	int sah_depth_limit = 48; // below this depth: median splits, which bound the total depth
 	int threads = 0;        // 0 = hardware concurrency (capped at 32)
+	// the collapse to 8-wide nodes: 1 = the cut of the binary tree that minimises the surface-area cost of the wide tree (dynamic
+	// programme over the number of roots a subtree is cut into), 0 = open the child with the largest area until there are eight
+	int optimal_cut = 1;
+	float wide_cost_node = 1.0f; // one 8-wide node fetched and tested
+	float wide_cost_tri = 1.5f;  // one triangle record fetched and tested (swept 0.3 .. 3 on the Cornell box, the 1M soup and a 490 k-triangle
+	                             // hall: 1.5 is the best or within noise of it on all three; 0.5 costs the Cornell box 17 %)
 };
 
 // The tree the traversal kernel walks: the BVH2 collapsed to 8 children per node, child boxes quantised to

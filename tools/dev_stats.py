@@ -14,6 +14,30 @@ if sys.argv[1] == "cornell":
     ctx.render_pass(0, 4); ctx.render_sync()
     rays = finish()
     m = len(rays)
+elif sys.argv[1] == "hall":  # the procedural hall's render rays of all bounces, with the oracle's ideal walk of the same tree beside them
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import oracle
+    from ray_tracer_amd import scene_io
+    from ray_tracer_amd.renderer import Renderer
+    paths = synth.atrium(os.path.join(tempfile.mkdtemp(), "hall"))
+    r = Renderer(0, seed=5); r.Load(paths["obj"])
+    mats, omm = scene_io.load_materials(paths["materials"]), scene_io.load_objmatmap(paths["objmatmap"])
+    assert r.LoadMaterials({name: mats[omm[name]] for name in omm})
+    nx, ny = 960, 540
+    r.cam.film_height = 0.024; r.cam.film_width = 0.024 * nx / ny; r.cam.aperture = 0.05
+    r.cam.SetLens(60.0, 0.4); r.cam.set_Camera([0.0, 1.3, 7.5], [0.0, 1.1, 0.0], [0, 1, 0])
+    ctx = r.ctx
+    ctx.set_camera(r.cam)
+    ctx.render_begin(nx, ny, 2, 30, capi.ALG_MIS, 1234)
+    finish = ctx.capture_rays(1 << 22)
+    ctx.render_pass(0, 2); ctx.render_sync()
+    rays = finish().copy()
+    m = len(rays)
+    wn, wt = ctx.wide_bvh()
+    sub = rays[np.random.default_rng(1).choice(m, 100000, replace=False)]
+    _, _, _, nv, nt = oracle.Scene(r.mesh).trace_wide(wn, wt, sub)
+    print("ideal ordered walk with distances: nodes/ray %.2f tris/ray %.2f" % (nv / len(sub), nt / len(sub)))
 else:
     n = int(sys.argv[2]); sigma = float(sys.argv[3]); m = int(sys.argv[4])
     ctx.upload_mesh(synth.soup(n, sigma))
