@@ -189,7 +189,7 @@ __device__ __forceinline__ float half_area(const Box4 &b)
 __global__ void __launch_bounds__(kBlock) k_fit(const BinNode *__restrict__ nodes, const int32_t *__restrict__ parent_of_node,
                                                 const int32_t *__restrict__ parent_of_leaf, const Box4 *__restrict__ tri_boxes,
                                                 const uint32_t *__restrict__ sorted_tri, int n, Box4 *node_boxes, float *node_cost,
-                                                uint8_t *__restrict__ as_leaf, unsigned int *__restrict__ arrived)
+                                                uint8_t *node_cut, uint8_t *__restrict__ as_leaf, unsigned int *__restrict__ arrived)
 {
 	const int leaf = blockIdx.x * kBlock + threadIdx.x;
 	if (leaf >= n) return;
@@ -203,14 +203,42 @@ __global__ void __launch_bounds__(kBlock) k_fit(const BinNode *__restrict__ node
 		// counter increment, is read from L2, not from a stale line of this CU's vector cache
 		const Box4 a = nd.left >= 0 ? node_boxes[nd.left] : tri_boxes[sorted_tri[~nd.left]];
 		const Box4 b = nd.right >= 0 ? node_boxes[nd.right] : tri_boxes[sorted_tri[~nd.right]];
-		const float ca = nd.left >= 0 ? node_cost[nd.left] : kCostTri * half_area(a);
-		const float cb = nd.right >= 0 ? node_cost[nd.right] : kCostTri * half_area(b);
+		// The cut into 8-wide nodes that minimises the surface-area cost of the wide tree, as in the host builder (bvh_builder.cpp,
+		// WideCut): cost[i - 1] is the cheapest way to represent the subtree by at most i roots, each a leaf child of at most
+		// kMaxLeaf triangles or an 8-wide node; cut[i - 1] = 0 means "as for i - 1" (a leaf when i = 1), k > 0 that the left
+		// subtree supplies k of the roots (of the eight children when i = 1).
+		float cl[7], cr[7];
+		for (int i = 0; i < 7; i++) {
+			cl[i] = nd.left >= 0 ? node_cost[7 * (size_t)nd.left + i] : kCostTri * half_area(a);
+			cr[i] = nd.right >= 0 ? node_cost[7 * (size_t)nd.right + i] : kCostTri * half_area(b);
+		}
 		const Box4 u = box_union(a, b);
 		const uint32_t count = nd.last - nd.first + 1u;
-		const float split = kCostNode * half_area(u) + ca + cb, whole = kCostTri * (float)count * half_area(u);
-		const bool leaf_wins = count <= kMaxLeaf && whole <= split;
+		const float whole = count <= kMaxLeaf ? kCostTri * (float)count * half_area(u) : FLT_MAX;
+		float best = FLT_MAX;
+		int bk = 1;
+		for (int k = 1; k <= 7; k++) {
+			const float v = cl[k - 1] + cr[7 - k];
+			if (v < best) { best = v; bk = k; }
+		}
+		const float split = kCostNode * half_area(u) + best;
+		const bool leaf_wins = whole <= split;
+		float c[7];
+		uint8_t d[7];
+		c[0] = leaf_wins ? whole : split;
+		d[0] = leaf_wins ? 0 : (uint8_t)bk;
+		for (int i = 2; i <= 7; i++) {
+			float v = c[i - 2];
+			int dk = 0;
+			for (int k = 1; k < i; k++) {
+				const float w = cl[k - 1] + cr[i - k - 1];
+				if (w < v) { v = w; dk = k; }
+			}
+			c[i - 1] = v;
+			d[i - 1] = (uint8_t)dk;
+		}
 		node_boxes[node] = u;
-		node_cost[node] = leaf_wins ? whole : split;
+		for (int i = 0; i < 7; i++) { node_cost[7 * (size_t)node + i] = c[i]; node_cut[7 * (size_t)node + i] = d[i]; }
 		as_leaf[node] = leaf_wins ? 1 : 0;
 		node = parent_of_node[node];
 	}
@@ -237,6 +265,7 @@ struct Counters {
 // one thread per wide node of the current level; queue entries: x = binary node (or ~position of a single leaf for
 // a one-triangle scene), y = index of the wide node to fill
 __global__ void __launch_bounds__(kBlock) k_collapse(const BinNode *__restrict__ bin, const Box4 *__restrict__ node_boxes, const uint8_t *__restrict__ as_leaf,
+                                                     const uint8_t *__restrict__ node_cut,
                                                      const Box4 *__restrict__ tri_boxes, const uint32_t *__restrict__ sorted_tri,
                                                      const uint2 *__restrict__ queue_in, uint32_t n_in, uint2 *__restrict__ queue_out,
                                                      WideNode *__restrict__ wide, uint32_t *__restrict__ leaf_tri, Counters *__restrict__ ctr)
@@ -260,12 +289,31 @@ __global__ void __launch_bounds__(kBlock) k_collapse(const BinNode *__restrict__
 		}
 		nk++;
 	};
-	{
+	const int root_k = node_cut[7 * (size_t)job.x];
+	if (root_k > 0) {
+		// the children the cost-minimising cut gives this node: the left subtree as root_k roots, the right one as 8 - root_k
+		const BinNode root = bin[job.x];
+		int32_t st_link[16];
+		int st_i[16], sp = 0;
+		st_link[sp] = root.right; st_i[sp++] = 8 - root_k;
+		st_link[sp] = root.left; st_i[sp++] = root_k;
+		while (sp > 0) {
+			const int32_t link = st_link[--sp];
+			int i = st_i[sp];
+			if (link < 0) { add(link); continue; } // a single triangle
+			while (i > 1 && node_cut[7 * (size_t)link + i - 1] == 0) i--;
+			if (i == 1) { add(link); continue; }
+			const int k = node_cut[7 * (size_t)link + i - 1];
+			const BinNode b2 = bin[link];
+			st_link[sp] = b2.right; st_i[sp++] = i - k;
+			st_link[sp] = b2.left; st_i[sp++] = k;
+		}
+	} else { // a subtree that is a leaf as a whole reaches here only as the root of a scene of a few triangles
 		const BinNode root = bin[job.x];
 		add(root.left);
 		add(root.right);
 	}
-	while (nk < 8) {
+	while (root_k == 0 && nk < 8) {
 		int best = -1;
 		float best_area = -1.0f;
 		for (int i = 0; i < nk; i++) {
@@ -432,7 +480,7 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	int32_t *parent_of_node = nullptr, *parent_of_leaf = nullptr;
 	unsigned int *arrived = nullptr;
 	float *node_cost = nullptr;
-	uint8_t *as_leaf = nullptr;
+	uint8_t *as_leaf = nullptr, *node_cut = nullptr;
 	Counters *ctr = nullptr;
 	uint2 *queue[2] = {nullptr, nullptr};
 	DB_TRY(dalloc(tri_boxes, n, tmp));
@@ -446,7 +494,8 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	DB_TRY(dalloc(parent_of_node, n, tmp));
 	DB_TRY(dalloc(parent_of_leaf, n, tmp));
 	DB_TRY(dalloc(arrived, n, tmp));
-	DB_TRY(dalloc(node_cost, n, tmp));
+	DB_TRY(dalloc(node_cost, 7 * (size_t)n, tmp));
+	DB_TRY(dalloc(node_cut, 7 * (size_t)n, tmp));
 	DB_TRY(dalloc(as_leaf, n, tmp));
 	DB_TRY(dalloc(ctr, 1, tmp));
 	DB_TRY(dalloc(queue[0], n, tmp));
@@ -466,7 +515,7 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	// ---- binary tree and its boxes
 	DB_TRY(hipMemsetAsync(arrived, 0, sizeof(unsigned int) * n, stream));
 	hipLaunchKernelGGL(k_hierarchy, dim3(blocks_n), dim3(kBlock), 0, stream, keys_sorted, (int)n, bin, parent_of_node, parent_of_leaf);
-	hipLaunchKernelGGL(k_fit, dim3(blocks_n), dim3(kBlock), 0, stream, bin, parent_of_node, parent_of_leaf, tri_boxes, sorted_tri, (int)n, node_boxes, node_cost, as_leaf, arrived);
+	hipLaunchKernelGGL(k_fit, dim3(blocks_n), dim3(kBlock), 0, stream, bin, parent_of_node, parent_of_leaf, tri_boxes, sorted_tri, (int)n, node_boxes, node_cost, node_cut, as_leaf, arrived);
 	DB_TRY(hipGetLastError());
 
 	// ---- collapse, level by level.  A wide node has at least two children, so there are at most n - 1 of them.
@@ -483,7 +532,7 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	while (n_in > 0) {
 		depth++;
 		if (depth > kTraceMaxDepth) { err = "build_bvh_device: tree deeper than the traversal stack (" + std::to_string(kTraceMaxDepth) + " levels)"; return hipErrorUnknown; }
-		hipLaunchKernelGGL(k_collapse, dim3((n_in + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, bin, node_boxes, as_leaf, tri_boxes, sorted_tri,
+		hipLaunchKernelGGL(k_collapse, dim3((n_in + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, bin, node_boxes, as_leaf, node_cut, tri_boxes, sorted_tri,
 		                   queue[cur], n_in, queue[cur ^ 1], wide, leaf_tri, ctr);
 		DB_TRY(hipMemcpyAsync(&h_ctr, ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, stream));
 		DB_TRY(hipStreamSynchronize(stream));
