@@ -142,11 +142,15 @@ def cpu_leg(args, ctx, capi, scenes, log):
     return out, oracle
 
 
-def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=5, host_buffer=False):
-    """incoherent closest hit on a random soup: Mrays/s, work units per ray, memory-side traffic from the committed PMC summary"""
+def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=5, host_buffer=False, builder=None):
+    """incoherent closest hit on a random soup: Mrays/s, work units per ray, memory-side traffic from the committed PMC summary.
+    builder: None leaves the library's choice (the GPU builder above 2^17 triangles); capi.BUILDER_HOST_SAH asks for the binned-SAH
+    tree, which takes 50 times longer to build and traces a soup 4-5 % faster"""
     t0 = time.time()
     mesh = synth.soup(n, sigma, seed=12345)
+    ctx.set_builder(capi.BUILDER_AUTO if builder is None else builder)
     ctx.upload_mesh(mesh)
+    ctx.set_builder(capi.BUILDER_AUTO)
     st = ctx.stats()
     log("soup %s: %d triangles uploaded in %.1f s (BVH build %.2f s, depth %d)" % (tag, n, time.time() - t0, st["bvh_build_seconds"], st["bvh_depth"]))
     rays = synth.incoherent_rays(m, seed=777, start=rank * m)
@@ -161,6 +165,7 @@ def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=
     ctx.render_sync()
     prof = ctx.profile_stop()["closest"]
     res = {"triangles": n, "sigma": sigma, "rays_per_launch": m, "launches": reps,
+           "builder": "library's choice (GPU: Morton radix tree, cost-minimising 8-wide cut)" if builder is None else "host binned SAH (rt_set_builder)",
            "kernel_ms_per_launch": prof["ms"] / reps, "mrays_per_s": m * reps / (prof["ms"] * 1e-3) / 1e6,
            "hit_rate": float((d_hits[:, 1] != -1).float().mean().item()), "bvh_build_s": st["bvh_build_seconds"],
            "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"], "device_mb": st["device_bytes"] / 1e6}
@@ -311,7 +316,8 @@ def main():
 
     soup = soup10 = None
     if not args.no_soup and world == 1:  # the single-GPU half of the metric: with N > 1 every rank would build and trace the same soups
-        soup = soup_leg(args.soup_tris, args.soup_sigma, args.soup_rays, "soup1m", ctx, capi, synth, oracle, torch, rank, log, host_buffer=True)
+        soup = soup_leg(args.soup_tris, args.soup_sigma, args.soup_rays, "soup1m", ctx, capi, synth, oracle, torch, rank, log, host_buffer=True,
+                        builder=capi.BUILDER_HOST_SAH)
         if not args.no_soup10m:
             soup10 = soup_leg(10_000_000, 0.002, args.soup_rays, "soup10m", ctx, capi, synth, oracle, torch, rank, log, reps=3)
 

@@ -147,7 +147,9 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	int builder = ctx->builder;
 	if (const char *s = std::getenv("MI355RT_BUILDER")) builder = std::strcmp(s, "device") == 0 ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
 	const bool auto_chosen = builder == RT_BUILDER_AUTO;
-	if (auto_chosen) builder = nt > 2000000 ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
+	// device above 2^17 fan triangles: with the cost-minimising cut its trees trace within 1-3 % of the host builder's on meshes (4.5 % on a
+	// triangle soup) and are built in 15 ms where the host takes 50-500 ms, more than a 1024-spp render of such a scene
+	if (auto_chosen) builder = nt > (1u << 17) ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
 	if (nt < 2) builder = RT_BUILDER_HOST_SAH; // the radix tree needs two leaves
 	// fp64 triangle data: v0 + face normal, v1 + v2.  The host builder writes the 128-byte leaf-ordered records of device_scene.h
 	// itself; the device builder takes the two halves in fan order and gathers the records on the GPU.

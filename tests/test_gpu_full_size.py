@@ -114,11 +114,12 @@ def test_4k_render_runs():
 
 
 def _check_against_oracle(ctx, mesh, rays, brute=300):
-    """ids and fp64 t of the GPU on `rays` against the oracle's exact polygon test: walked through the product's own BVH2 for all
-    rays (topology shared, arithmetic independent), and by brute force over every polygon for a sample (nothing shared)"""
+    """ids and fp64 t of the GPU on `rays` against the oracle's exact polygon test: walked through the product's own 8-wide tree for
+    all rays (topology shared, arithmetic independent; whichever builder made it), and by brute force over every polygon for a
+    sample (nothing shared)"""
     sc = oracle.Scene(mesh)
-    nodes, tri_index = ctx.bvh2()
-    poly, tri, t, _, _ = sc.trace_bvh2(nodes, tri_index, rays, nthreads=16)
+    nodes, tri_index = ctx.wide_bvh()
+    poly, tri, t, _, _ = sc.trace_wide(nodes, tri_index, rays, nthreads=16)
     hits, t64 = ctx.trace_closest(rays, want_t64=True)
     gp = hits["prim"].astype(np.int64)
     gp[hits["prim"] == capi.MISS] = -1

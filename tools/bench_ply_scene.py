@@ -89,12 +89,12 @@ def main():
         ctx.render_sync()
         rays = finish()
         sc = oracle.Scene(mesh)
-        nodes, tri_index = ctx.bvh2()
-        poly, tri, t, nv, nt = sc.trace_bvh2(nodes, tri_index, rays, nthreads=16)
+        nodes, tri_index = ctx.wide_bvh()
+        poly, tri, t, nv, nt = sc.trace_wide(nodes, tri_index, rays, nthreads=16)
         hits, t64 = ctx.trace_closest(rays, want_t64=True)
         gp = hits["prim"].astype(np.int64)
         gp[hits["prim"] == capi.MISS] = -1
-        bpr = bench.b_ray(nv / len(rays), nt / len(rays))
+        bpr = bench.b_ray_wide(nv / len(rays), nt / len(rays), 128.0)
         out.update(nodes_per_ray=nv / len(rays), tris_per_ray=nt / len(rays), b_ray=bpr, parity_rays=int(len(rays)),
                    parity_prim_mismatch=int((gp != poly).sum()), parity_t_mismatch=int((t64 != t).sum()),
                    roofline_frac=k["items"] * bpr / (k["ms"] * 1e-3) / bench.HBM_PEAK)

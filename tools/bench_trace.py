@@ -63,7 +63,10 @@ rays = np.concatenate([rays, rays[::-1], rays])[: 1 << 24]
 g, h = rate(rays)
 ga, ha = rate(rays, any_hit=True)
 out = "%-28s cornell %d rays: closest %.2f Grays/s [%s] any %.2f [%s]" % (tag, len(rays), g, h, ga, ha)
+if "MI355RT_BUILDER" not in os.environ:
+    ctx.set_builder(capi.BUILDER_HOST_SAH)  # as bench.py's 1M leg
 ctx.upload_mesh(synth.soup(1_000_000, 0.004, seed=12345))
+ctx.set_builder(capi.BUILDER_AUTO)
 g, h = rate(synth.incoherent_rays(1 << 24, seed=777))
 out += " | soup1m closest %.3f [%s]" % (g, h)
 if "--soup10m" in sys.argv:

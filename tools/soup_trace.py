@@ -13,6 +13,7 @@ n, sigma = int(sys.argv[1]), float(sys.argv[2])
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 24
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 ctx = capi.Context(0)
+ctx.set_builder(capi.BUILDER_HOST_SAH if n < 2_000_000 else capi.BUILDER_AUTO)  # as bench.py's two soup legs
 ctx.upload_mesh(synth.soup(n, sigma, seed=12345))
 d_rays = torch.from_numpy(synth.incoherent_rays(m, seed=777)).cuda()
 d_hits = torch.empty((m, 4), dtype=torch.int32, device="cuda")
