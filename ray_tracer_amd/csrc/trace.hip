@@ -8,6 +8,7 @@
 // The traversal stack holds at most `depth` links; it lives in LDS laid out [entry][lane]
 // (conflict-free ds_read/ds_write_b32) when the tree is shallow enough, else in per-lane scratch.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
 #include <cstdlib>
@@ -23,19 +24,12 @@ namespace {
 #ifndef TRACE_LDS_STACK
 #define TRACE_LDS_STACK 16
 #endif
-// idle lanes before a wave takes new rays / descending lanes below which the node phase ends; _R: scenes served by the caches, _S: others
-#ifndef TRACE_REFILL_MIN_R
-#define TRACE_REFILL_MIN_R 16
-#endif
-#ifndef TRACE_REFILL_MIN_S
-#define TRACE_REFILL_MIN_S 8
-#endif
-#ifndef TRACE_NODE_MIN_LANES_R
-#define TRACE_NODE_MIN_LANES_R 62
-#endif
-#ifndef TRACE_NODE_MIN_LANES_S
-#define TRACE_NODE_MIN_LANES_S 48
-#endif
+// Two thresholds steer a wave, both launch arguments (they sit in scalar registers): the number of idle lanes at which it takes new
+// rays, and the number of descending lanes below which it leaves the node phase for the triangle phase.  What is best depends on
+// how many node steps a ray needs: a ray of the Cornell box needs 1.7, rays end in bulk, and late refills / early exits win (16 / 62);
+// a ray inside a 490 k-triangle hall needs 13, and 8 / 56 is 24 % faster there (and 2.6 % slower on the box); a soup that waits for
+// memory wants 8 / 48 (62 costs it 18 %).
+struct TraceTuning { uint32_t refill_min, node_min_lanes; };
 #ifndef TRACE_COOP_LEAF
 #define TRACE_COOP_LEAF 1
 #endif
@@ -188,7 +182,7 @@ __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return (floa
 // descending; the fp64 triangle phase runs when a lane holds two parked groups or has run out of nodes,
 // so that it runs with most lanes holding work.
 template <bool LDS_STACK, bool ANY, bool WT, bool RESIDENT>
-__global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGeom g, const rt_ray *__restrict__ rays, uint64_t n_bound,
+__global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGeom g, TraceTuning tune, const rt_ray *__restrict__ rays, uint64_t n_bound,
                                                   rt_hit *__restrict__ hits, double *__restrict__ t64,
                                                   uint8_t *__restrict__ any_out, const uint32_t *__restrict__ n_dev)
 {
@@ -243,7 +237,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 		const unsigned long long idle = __ballot(!active);
 		if (idle != 0 && chunk_lo + (next >> 6) * n_waves + wave_id < chunk_hi) {
 			const int nidle = __popcll(idle);
-			if (nidle >= (RESIDENT ? TRACE_REFILL_MIN_R : TRACE_REFILL_MIN_S)) {
+			if (nidle >= (int)tune.refill_min) {
 				const uint64_t seq = next + (uint64_t)__popcll(idle & lt);
 				const uint64_t chunk = chunk_lo + (seq >> 6) * n_waves + wave_id;
 				const uint64_t mine = chunk * 64 + (seq & 63);
@@ -373,7 +367,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					else { l1_base = h1.y; l1_m0 = h1.z; l1_m1 = h1.w; l1_hits = leaf_hits; }
 				}
 				if (__ballot(l0_hits == 0) == 0) break; // every lane still descending already holds triangles to test
-				if (__popcll(__ballot(true)) < (RESIDENT ? TRACE_NODE_MIN_LANES_R : TRACE_NODE_MIN_LANES_S)) break; // too few lanes left descending
+				if (__popcll(__ballot(true)) < (int)tune.node_min_lanes) break; // too few lanes left descending
 			}
 #if TRACE_COOP_LEAF
 		}
@@ -592,7 +586,11 @@ hipError_t launch_trace(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, r
 	bool resident = g.tri_stride == 7 || g.surface_rays != 0;
 	static const char *const force = std::getenv("MI355RT_TRACE_RESIDENT"); // experiments: 0 / 1 overrides the choice
 	if (force && (force[0] == '0' || force[0] == '1')) resident = force[0] == '1';
-#define TRACE_LAUNCH(L, W, R) hipLaunchKernelGGL((k_trace<L, ANY, W, R>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, d_rays, n, d_hits, d_t64, d_any, d_n)
+	TraceTuning tune = g.tri_stride == 7 ? TraceTuning{16u, 62u} : (g.surface_rays ? TraceTuning{8u, 56u} : TraceTuning{8u, 48u});
+	static const char *const t_refill = std::getenv("MI355RT_TRACE_REFILL"), *const t_lanes = std::getenv("MI355RT_TRACE_NODE_LANES"); // experiments
+	if (t_refill) tune.refill_min = (uint32_t)std::max(1, std::min(64, std::atoi(t_refill)));
+	if (t_lanes) tune.node_min_lanes = (uint32_t)std::max(0, std::min(64, std::atoi(t_lanes)));
+#define TRACE_LAUNCH(L, W, R) hipLaunchKernelGGL((k_trace<L, ANY, W, R>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, tune, d_rays, n, d_hits, d_t64, d_any, d_n)
 #define TRACE_LAUNCH_R(L, W) do { if (resident) TRACE_LAUNCH(L, W, true); else TRACE_LAUNCH(L, W, false); } while (0)
 	if (g.watertight) { if (lds) TRACE_LAUNCH_R(true, true); else TRACE_LAUNCH_R(false, true); }
 	else { if (lds) TRACE_LAUNCH_R(true, false); else TRACE_LAUNCH_R(false, false); }
