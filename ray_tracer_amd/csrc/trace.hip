@@ -170,6 +170,28 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
 	return (uint32_t)x;
 }
 
+// the same for the maximum of unsigned values (0 is the identity: lanes that a step does not reach keep their value)
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v)
+{
+	int x = (int)v;
+	x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));
+	x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));
+	x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true));
+	x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true));
+	x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+	x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
+	return (uint32_t)x;
+}
+
+// Triangle counts of four leaf children as four bytes: meta holds (count << 5 | offset) per child, hits4 says which of the four the
+// ray's box test hit (bit i -> byte i: multiplying by 1 + 2^7 + 2^14 + 2^21 puts bit i at position 8 i, among others that the mask drops)
+__device__ __forceinline__ uint32_t child_counts(uint32_t meta4, uint32_t hits4)
+{
+	const uint32_t sel = ((hits4 & 0xFu) * 0x00204081u) & 0x01010101u;
+	return ((meta4 >> 5) & 0x07070707u) & (sel * 7u);
+}
+__device__ __forceinline__ uint32_t byte_sum(uint32_t c) { return (c * 0x01010101u) >> 24; } // sums stay below 256: at most 4 x 7
+
 __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); } // v_cvt_f32_ubyteK
 
 // Persistent waves: each wave owns an interleaved share of the 64-ray chunks and keeps its 64 lanes busy by
@@ -199,7 +221,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 #define TRACE_LAP(k) do { } while (0)
 #endif
 #if TRACE_COOP_LEAF
-	__shared__ uint32_t coop_li[kBlock / 64][64], coop_owner[kBlock / 64][64];
+	__shared__ uint32_t coop_owner[kBlock / 64][64];
 	__shared__ unsigned long long coop_t[kBlock / 64][64], coop_id[kBlock / 64][64];
 #endif
 	__shared__ uint32_t lds_base[LDS_STACK ? kLdsStack * kBlock : 1];
@@ -374,17 +396,15 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 		TRACE_LAP(1); // node phase
 		// ---- triangle phase, shared by the whole wave.  Lanes hold very different numbers of parked triangles (0 to 8 and more), so
 		// a per-lane loop runs the fp64 tests with a quarter of the lanes.  Instead every (ray, triangle) pair of the wave gets a lane of
-		// its own: pairs are numbered by a prefix sum over the per-lane counts, written to LDS (leaf position + owner lane), and lane j
-		// tests pair j with the owner's ray fetched by cross-lane reads.  Hits are merged per owner with LDS atomics: minimum of the
+		// its own: pairs are numbered by a prefix sum over the per-lane counts, and lane j tests pair j, which it finds in its owner's
+		// registers (see below), with the owner's ray fetched by cross-lane reads.  Hits are merged per owner with LDS atomics: minimum of the
 		// bit pattern of t (positive doubles order like their bits), then, among the hits at that t, minimum of (fan triangle << 32 | leaf
 		// position), which is the tie rule "lowest fan triangle".  Idle lanes take part as workers.
 		{
 			const int wv = threadIdx.x >> 6;
 			uint32_t n_mine = 0;
-			if (active) {
-				for (uint32_t h = l0_hits; h; h &= h - 1u) { const uint32_t c = (uint32_t)__ffs((int)h) - 1u; n_mine += (((c < 4 ? l0_m0 : l0_m1) >> (8 * (c & 3))) & 0xFFu) >> 5; }
-				for (uint32_t h = l1_hits; h; h &= h - 1u) { const uint32_t c = (uint32_t)__ffs((int)h) - 1u; n_mine += (((c < 4 ? l1_m0 : l1_m1) >> (8 * (c & 3))) & 0xFFu) >> 5; }
-			}
+			if (active) n_mine = byte_sum(child_counts(l0_m0, l0_hits)) + byte_sum(child_counts(l0_m1, l0_hits >> 4)) +
+			                     byte_sum(child_counts(l1_m0, l1_hits)) + byte_sum(child_counts(l1_m1, l1_hits >> 4));
 			const uint32_t incl = wave_inclusive_sum(n_mine);
 			const uint32_t off = incl - n_mine, total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 			if (total != 0) {
@@ -392,28 +412,43 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				unsigned long long my_t = (unsigned long long)__double_as_longlong(t_best);
 				unsigned long long my_id = best == RT_MISS ? none_id : (((unsigned long long)best_tri << 32) | best);
 				if (n_mine) { coop_t[wv][lane] = my_t; coop_id[wv][lane] = my_id; }
+				uint32_t carry = 0; // owner (lane + 1) of the pair just before this round's first
 				for (uint32_t r0 = 0; r0 < total; r0 += 64) {
-					// owners publish the pairs of this round
-					if (n_mine && off < r0 + 64 && off + n_mine > r0) {
-						uint32_t q = off;
-						for (int grp = 0; grp < 2; grp++) {
-							const uint32_t gb = grp ? l1_base : l0_base, m0 = grp ? l1_m0 : l0_m0, m1 = grp ? l1_m1 : l0_m1;
-							for (uint32_t h = grp ? l1_hits : l0_hits; h; h &= h - 1u) {
-								const uint32_t c = (uint32_t)__ffs((int)h) - 1u;
-								const uint32_t meta = ((c < 4 ? m0 : m1) >> (8 * (c & 3))) & 0xFFu;
-								const uint32_t first = gb + (meta & 31u), count = meta >> 5;
-								for (uint32_t k = 0; k < count; k++, q++)
-									if (q - r0 < 64u) { coop_li[wv][q - r0] = first + k; coop_owner[wv][q - r0] = (uint32_t)lane; }
-							}
-						}
-					}
+					// Pair q belongs to the lane whose run of pairs [off, off + n_mine) contains it.  Every owner whose run starts in this
+					// round marks the start, a running maximum over the marks (data-parallel moves, no loop) tells each worker its owner,
+					// and the worker works out which of the owner's parked triangles it has from the owner's registers: no lane walks
+					// through its own list (that loop ran every wave for its longest list, 100-200 instructions per round).
+					coop_owner[wv][lane] = 0u;
+					if (n_mine && off >= r0 && off < r0 + 64u) coop_owner[wv][off - r0] = (uint32_t)lane + 1u;
 					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 					__builtin_amdgcn_wave_barrier();
-					TRACE_LAP(2); // counting, prefix sum, publishing the pairs
 					// workers: one pair each
 					const bool work = r0 + (uint32_t)lane < total;
-					const uint32_t o = work ? coop_owner[wv][lane] : (uint32_t)lane;
-					const uint32_t li = work ? coop_li[wv][lane] : 0u;
+					const uint32_t mark = max(wave_inclusive_max(coop_owner[wv][lane]), carry);
+					carry = (uint32_t)__builtin_amdgcn_readlane((int)mark, 63);
+					const uint32_t o = work ? mark - 1u : (uint32_t)lane;
+					uint32_t li = 0;
+					{
+						const uint32_t k = r0 + (uint32_t)lane - (uint32_t)__shfl((int)off, (int)o); // position in the owner's run
+						const uint32_t o_hits = (uint32_t)__shfl((int)(l0_hits | (l1_hits << 8)), (int)o);
+						const uint32_t m00 = (uint32_t)__shfl((int)l0_m0, (int)o), m01 = (uint32_t)__shfl((int)l0_m1, (int)o);
+						const uint32_t m10 = (uint32_t)__shfl((int)l1_m0, (int)o), m11 = (uint32_t)__shfl((int)l1_m1, (int)o);
+						const uint32_t b0 = (uint32_t)__shfl((int)l0_base, (int)o), b1 = (uint32_t)__shfl((int)l1_base, (int)o);
+						const uint32_t c00 = child_counts(m00, o_hits), c01 = child_counts(m01, o_hits >> 4);
+						const uint32_t c10 = child_counts(m10, o_hits >> 8), c11 = child_counts(m11, o_hits >> 12);
+						const uint32_t s1 = byte_sum(c00), s2 = s1 + byte_sum(c01), s3 = s2 + byte_sum(c10);
+						// which four children, then which of the four: the first whose running count exceeds the position
+						const uint32_t d = (k >= s1 ? 1u : 0u) + (k >= s2 ? 1u : 0u) + (k >= s3 ? 1u : 0u);
+						const uint32_t kk = k - (d == 0 ? 0u : (d == 1 ? s1 : (d == 2 ? s2 : s3)));
+						const uint32_t c = d == 0 ? c00 : (d == 1 ? c01 : (d == 2 ? c10 : c11));
+						const uint32_t m = d == 0 ? m00 : (d == 1 ? m01 : (d == 2 ? m10 : m11));
+						const uint32_t p = c * 0x01010101u; // byte i = count of children 0..i
+						const uint32_t i = (kk >= (p & 0xFFu) ? 1u : 0u) + (kk >= ((p >> 8) & 0xFFu) ? 1u : 0u) + (kk >= ((p >> 16) & 0xFFu) ? 1u : 0u);
+						const uint32_t before = ((p >> (8 * i)) & 0xFFu) - ((c >> (8 * i)) & 0xFFu);
+						li = (d < 2 ? b0 : b1) + (((m >> (8 * i)) & 0xFFu) & 31u) + (kk - before);
+						if (!work) li = 0;
+					}
+					TRACE_LAP(2); // counting, prefix sum, finding each worker's pair
 					RayD r;
 					r.ox = __shfl(ox, (int)o); r.oy = __shfl(oy, (int)o); r.oz = __shfl(oz, (int)o);
 					r.dx = __shfl(dx, (int)o); r.dy = __shfl(dy, (int)o); r.dz = __shfl(dz, (int)o);
