@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				float ayn = fmaf(-wid, fabsf(ay), ay), ayf = fmaf(wid, fabsf(ay), ay);
 				float azn = fmaf(-wid, fabsf(az), az), azf = fmaf(wid, fabsf(az), az);
 				{ // an axis the ray does not move along: widen by one cell (k* is then +cell * kBigInv).  Branch-free on purpose:
-				  // a conditional block here splits the node test and costs 4-11 % on every ray, six FMAs cost nothing measurable
+				  // a conditional block here splits the node test and costs 4-11 % on every ray (even one the whole wave skips: -16 % on a soup), six FMAs cost nothing measurable
 					const float wx = (oct & 8u) ? 1.0f : 0.0f, wy = (oct & 16u) ? 1.0f : 0.0f, wz = (oct & 32u) ? 1.0f : 0.0f;
 					axn = fmaf(-wx, kx, axn); axf = fmaf(wx, kx, axf);
 					ayn = fmaf(-wy, ky, ayn); ayf = fmaf(wy, ky, ayf);
