@@ -8,7 +8,7 @@
 //   k_morton        63-bit Morton key of each box centre (21 bits per axis)
 //   radix sort      hipcub::DeviceRadixSort (key, triangle id)
 //   k_hierarchy     binary radix tree over the sorted keys; ties between equal keys are broken by position
-//   k_fit           leaves walk up; the second thread to reach a node unions its children's boxes
+//   k_fit_*         bottom up in rounds (one launch per level of readiness): boxes, subtree costs, the cut into wide nodes
 //   k_collapse      one thread per wide node and level: opens the child with the largest area until there are 8,
 //                   assigns slots by octant, quantises the child boxes, reserves its interior children and its leaf
 //                   triangles with one atomic each, and queues the interior children for the next level
@@ -28,6 +28,7 @@ namespace mi355rt {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr unsigned kStrideBlocks = 4096; // grid of the kernels that walk through their input in strides
 constexpr uint32_t kMaxLeaf = 4; // triangles per leaf child: a wide node addresses 8 x 4 = 32 triangles
 constexpr float kCostNode = 1.0f, kCostTri = 1.5f; // surface-area heuristic: one interior step, one triangle test
 
@@ -62,9 +63,8 @@ struct Box4 {
 __global__ void __launch_bounds__(kBlock) k_tri_boxes(const double2 *__restrict__ tri_a, const double2 *__restrict__ tri_b, uint32_t n,
                                                       Box4 *__restrict__ boxes, int *__restrict__ bounds)
 {
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-	if (i < n) {
+	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
 		const double2 a0 = tri_a[3 * (size_t)i], a1 = tri_a[3 * (size_t)i + 1];
 		const double2 b0 = tri_b[3 * (size_t)i], b1 = tri_b[3 * (size_t)i + 1], b2 = tri_b[3 * (size_t)i + 2];
 		const double vx[3] = {a0.x, b0.x, b1.y}, vy[3] = {a0.y, b0.y, b2.x}, vz[3] = {a1.x, b1.x, b2.y};
@@ -74,20 +74,29 @@ __global__ void __launch_bounds__(kBlock) k_tri_boxes(const double2 *__restrict_
 		b.hi = make_float4(__double2float_ru(fmax(fmax(vx[0], vx[1]), vx[2])), __double2float_ru(fmax(fmax(vy[0], vy[1]), vy[2])),
 		                   __double2float_ru(fmax(fmax(vz[0], vz[1]), vz[2])), 0.0f);
 		boxes[i] = b;
-		clo[0] = chi[0] = 0.5f * (b.lo.x + b.hi.x);
-		clo[1] = chi[1] = 0.5f * (b.lo.y + b.hi.y);
-		clo[2] = chi[2] = 0.5f * (b.lo.z + b.hi.z);
+		const float cx = 0.5f * (b.lo.x + b.hi.x), cy = 0.5f * (b.lo.y + b.hi.y), cz = 0.5f * (b.lo.z + b.hi.z);
+		clo[0] = fminf(clo[0], cx); chi[0] = fmaxf(chi[0], cx);
+		clo[1] = fminf(clo[1], cy); chi[1] = fmaxf(chi[1], cy);
+		clo[2] = fminf(clo[2], cz); chi[2] = fmaxf(chi[2], cz);
 	}
-	// wave reduction, then one atomic per wave and component
+	// wave reduction, workgroup reduction through LDS, then one atomic per workgroup and component: the grid is a few thousand
+	// workgroups, because atomics on one address retire one after the other (one per wave of a 10 M-triangle launch took 10 ms)
+	__shared__ float part[2][3][kBlock / 64];
 	for (int a = 0; a < 3; a++) {
 		float lo = clo[a], hi = chi[a];
 		for (int off = 32; off > 0; off >>= 1) {
 			lo = fminf(lo, __shfl_xor(lo, off));
 			hi = fmaxf(hi, __shfl_xor(hi, off));
 		}
-		if ((threadIdx.x & 63) == 0 && lo <= hi) {
-			atomicMin(&bounds[a], float_to_ordered(lo));
-			atomicMax(&bounds[3 + a], float_to_ordered(hi));
+		if ((threadIdx.x & 63) == 0) { part[0][a][threadIdx.x >> 6] = lo; part[1][a][threadIdx.x >> 6] = hi; }
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) {
+		float lo = part[0][threadIdx.x][0], hi = part[1][threadIdx.x][0];
+		for (int w = 1; w < kBlock / 64; w++) { lo = fminf(lo, part[0][threadIdx.x][w]); hi = fmaxf(hi, part[1][threadIdx.x][w]); }
+		if (lo <= hi) {
+			atomicMin(&bounds[threadIdx.x], float_to_ordered(lo));
+			atomicMax(&bounds[3 + threadIdx.x], float_to_ordered(hi));
 		}
 	}
 }
@@ -183,64 +192,107 @@ __device__ __forceinline__ float half_area(const Box4 &b)
 	return dx * dy + dy * dz + dz * dx;
 }
 
-// Leaves walk up; the second thread to reach a node unions its children's boxes.  On the way the surface-area cost of
-// each subtree is settled bottom up: a subtree of at most kMaxLeaf triangles becomes one leaf child of a wide node when
-// testing all its triangles is estimated cheaper than descending further (same constants as the host builder).
-__global__ void __launch_bounds__(kBlock) k_fit(const BinNode *__restrict__ nodes, const int32_t *__restrict__ parent_of_node,
-                                                const int32_t *__restrict__ parent_of_leaf, const Box4 *__restrict__ tri_boxes,
-                                                const uint32_t *__restrict__ sorted_tri, int n, Box4 *node_boxes, float *node_cost,
-                                                uint8_t *node_cut, uint8_t *__restrict__ as_leaf, unsigned int *__restrict__ arrived)
+// Bottom-up fit in rounds.  A node is ready once both of its children are settled; the ready nodes of one round are one launch,
+// and whoever settles the second child of a node puts that node on the next round's list.  The number of rounds is the height of
+// the binary tree.  (A single launch in which every leaf walks up and the second thread to arrive at a node carries on needs a
+// device-wide fence per node, and on this chip, where each of the eight dies has its own L2, such a fence writes back and
+// invalidates that L2: 92 ms for 10 M triangles against 4 ms for the rounds.)
+//
+// On the way the surface-area cost of each subtree is settled: a subtree of at most kMaxLeaf triangles becomes one leaf child of a
+// wide node when testing all its triangles is estimated cheaper than descending further (same constants as the host builder).
+
+// appends the nodes of the calling threads that have one (has) to list[*tail...]: one atomic per workgroup
+__device__ __forceinline__ void append_ready(bool has, uint32_t node, uint32_t *__restrict__ list, unsigned int *__restrict__ tail)
 {
-	const int leaf = blockIdx.x * kBlock + threadIdx.x;
-	if (leaf >= n) return;
-	int node = parent_of_leaf[leaf];
-	while (node >= 0) {
-		__threadfence(); // the boxes written below this node must be visible to whoever arrives second
-		if (atomicAdd(&arrived[node], 1u) == 0u) return; // first to arrive: the sibling subtree is not finished yet
-		__threadfence();
-		const BinNode nd = nodes[node];
-		// the fence above is the acquire side: the sibling's box, written on another CU before its own fence and
-		// counter increment, is read from L2, not from a stale line of this CU's vector cache
-		const Box4 a = nd.left >= 0 ? node_boxes[nd.left] : tri_boxes[sorted_tri[~nd.left]];
-		const Box4 b = nd.right >= 0 ? node_boxes[nd.right] : tri_boxes[sorted_tri[~nd.right]];
-		// The cut into 8-wide nodes that minimises the surface-area cost of the wide tree, as in the host builder (bvh_builder.cpp,
-		// WideCut): cost[i - 1] is the cheapest way to represent the subtree by at most i roots, each a leaf child of at most
-		// kMaxLeaf triangles or an 8-wide node; cut[i - 1] = 0 means "as for i - 1" (a leaf when i = 1), k > 0 that the left
-		// subtree supplies k of the roots (of the eight children when i = 1).
-		float cl[7], cr[7];
-		for (int i = 0; i < 7; i++) {
-			cl[i] = nd.left >= 0 ? node_cost[7 * (size_t)nd.left + i] : kCostTri * half_area(a);
-			cr[i] = nd.right >= 0 ? node_cost[7 * (size_t)nd.right + i] : kCostTri * half_area(b);
+	__shared__ unsigned int wave_count[kBlock / 64], wave_base[kBlock / 64];
+	const unsigned long long m = __ballot(has);
+	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	__syncthreads(); // the arrays may still be read by the previous call
+	if (lane == 0) wave_count[wv] = (unsigned int)__popcll(m);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned int total = 0;
+		for (int w = 0; w < kBlock / 64; w++) { wave_base[w] = total; total += wave_count[w]; }
+		const unsigned int base = total ? atomicAdd(tail, total) : 0u;
+		for (int w = 0; w < kBlock / 64; w++) wave_base[w] += base;
+	}
+	__syncthreads();
+	if (has) list[wave_base[wv] + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = node;
+}
+
+__global__ void __launch_bounds__(kBlock) k_fit_leaves(const int32_t *__restrict__ parent_of_leaf, int n, unsigned int *__restrict__ arrived,
+                                                       uint32_t *__restrict__ ready, unsigned int *__restrict__ tail)
+{
+	const int rounds = (n + (int)(gridDim.x * kBlock) - 1) / (int)(gridDim.x * kBlock);
+	for (int r = 0; r < rounds; r++) { // every thread takes part in every append
+		const int leaf = (int)((r * gridDim.x + blockIdx.x) * kBlock + threadIdx.x);
+		bool second = false;
+		int p = 0;
+		if (leaf < n) {
+			p = parent_of_leaf[leaf];
+			second = atomicAdd(&arrived[p], 1u) == 1u;
 		}
-		const Box4 u = box_union(a, b);
-		const uint32_t count = nd.last - nd.first + 1u;
-		const float whole = count <= kMaxLeaf ? kCostTri * (float)count * half_area(u) : FLT_MAX;
-		float best = FLT_MAX;
-		int bk = 1;
-		for (int k = 1; k <= 7; k++) {
-			const float v = cl[k - 1] + cr[7 - k];
-			if (v < best) { best = v; bk = k; }
-		}
-		const float split = kCostNode * half_area(u) + best;
-		const bool leaf_wins = whole <= split;
-		float c[7];
-		uint8_t d[7];
-		c[0] = leaf_wins ? whole : split;
-		d[0] = leaf_wins ? 0 : (uint8_t)bk;
-		for (int i = 2; i <= 7; i++) {
-			float v = c[i - 2];
-			int dk = 0;
-			for (int k = 1; k < i; k++) {
-				const float w = cl[k - 1] + cr[i - k - 1];
-				if (w < v) { v = w; dk = k; }
+		append_ready(second, (uint32_t)p, ready, tail);
+	}
+}
+
+__global__ void __launch_bounds__(kBlock) k_fit_round(const BinNode *__restrict__ nodes, const int32_t *__restrict__ parent_of_node,
+                                                      const Box4 *__restrict__ tri_boxes, const uint32_t *__restrict__ sorted_tri,
+                                                      const uint32_t *__restrict__ ready_in, unsigned int n_in, Box4 *node_boxes, float *node_cost,
+                                                      uint8_t *node_cut, uint8_t *__restrict__ as_leaf, unsigned int *__restrict__ arrived,
+                                                      uint32_t *__restrict__ ready_out, unsigned int *__restrict__ tail)
+{
+	const unsigned int rounds = (n_in + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+	for (unsigned int r = 0; r < rounds; r++) {
+		const unsigned int qi = (r * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+		bool second = false;
+		int up = 0;
+		if (qi < n_in) {
+			const int node = (int)ready_in[qi];
+			const BinNode nd = nodes[node];
+			const Box4 a = nd.left >= 0 ? node_boxes[nd.left] : tri_boxes[sorted_tri[~nd.left]];
+			const Box4 b = nd.right >= 0 ? node_boxes[nd.right] : tri_boxes[sorted_tri[~nd.right]];
+			// The cut into 8-wide nodes that minimises the surface-area cost of the wide tree, as in the host builder (bvh_builder.cpp,
+			// WideCut): cost[i - 1] is the cheapest way to represent the subtree by at most i roots, each a leaf child of at most
+			// kMaxLeaf triangles or an 8-wide node; cut[i - 1] = 0 means "as for i - 1" (a leaf when i = 1), k > 0 that the left
+			// subtree supplies k of the roots (of the eight children when i = 1).
+			float cl[7], cr[7];
+			for (int i = 0; i < 7; i++) {
+				cl[i] = nd.left >= 0 ? node_cost[7 * (size_t)nd.left + i] : kCostTri * half_area(a);
+				cr[i] = nd.right >= 0 ? node_cost[7 * (size_t)nd.right + i] : kCostTri * half_area(b);
 			}
-			c[i - 1] = v;
-			d[i - 1] = (uint8_t)dk;
+			const Box4 u = box_union(a, b);
+			const uint32_t count = nd.last - nd.first + 1u;
+			const float whole = count <= kMaxLeaf ? kCostTri * (float)count * half_area(u) : FLT_MAX;
+			float best = FLT_MAX;
+			int bk = 1;
+			for (int k = 1; k <= 7; k++) {
+				const float v = cl[k - 1] + cr[7 - k];
+				if (v < best) { best = v; bk = k; }
+			}
+			const float split = kCostNode * half_area(u) + best;
+			const bool leaf_wins = whole <= split;
+			float c[7];
+			uint8_t d[7];
+			c[0] = leaf_wins ? whole : split;
+			d[0] = leaf_wins ? 0 : (uint8_t)bk;
+			for (int i = 2; i <= 7; i++) {
+				float v = c[i - 2];
+				int dk = 0;
+				for (int k = 1; k < i; k++) {
+					const float w = cl[k - 1] + cr[i - k - 1];
+					if (w < v) { v = w; dk = k; }
+				}
+				c[i - 1] = v;
+				d[i - 1] = (uint8_t)dk;
+			}
+			node_boxes[node] = u;
+			for (int i = 0; i < 7; i++) { node_cost[7 * (size_t)node + i] = c[i]; node_cut[7 * (size_t)node + i] = d[i]; }
+			as_leaf[node] = leaf_wins ? 1 : 0;
+			up = parent_of_node[node];
+			if (up >= 0) second = atomicAdd(&arrived[up], 1u) == 1u; // the other child was settled in an earlier launch, or is settled in this one by whoever came first
 		}
-		node_boxes[node] = u;
-		for (int i = 0; i < 7; i++) { node_cost[7 * (size_t)node + i] = c[i]; node_cut[7 * (size_t)node + i] = d[i]; }
-		as_leaf[node] = leaf_wins ? 1 : 0;
-		node = parent_of_node[node];
+		append_ready(second, (uint32_t)up, ready_out, tail);
 	}
 }
 
@@ -504,7 +556,7 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	// ---- boxes, keys, sort
 	const int init_bounds[6] = {0x7F7FFFFF, 0x7F7FFFFF, 0x7F7FFFFF, (int)0x80800000, (int)0x80800000, (int)0x80800000}; // +FLT_MAX x3, ordered(-FLT_MAX) x3
 	DB_TRY(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
-	hipLaunchKernelGGL(k_tri_boxes, dim3(blocks_n), dim3(kBlock), 0, stream, (const double2 *)d_tri_a_fan, (const double2 *)d_tri_b_fan, n, tri_boxes, bounds);
+	hipLaunchKernelGGL(k_tri_boxes, dim3(std::min(blocks_n, kStrideBlocks)), dim3(kBlock), 0, stream, (const double2 *)d_tri_a_fan, (const double2 *)d_tri_b_fan, n, tri_boxes, bounds);
 	hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(kBlock), 0, stream, tri_boxes, n, bounds, keys, vals);
 	size_t sort_bytes = 0;
 	DB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys_sorted, vals, sorted_tri, (int)n, 0, 63, stream));
@@ -515,8 +567,29 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	// ---- binary tree and its boxes
 	DB_TRY(hipMemsetAsync(arrived, 0, sizeof(unsigned int) * n, stream));
 	hipLaunchKernelGGL(k_hierarchy, dim3(blocks_n), dim3(kBlock), 0, stream, keys_sorted, (int)n, bin, parent_of_node, parent_of_leaf);
-	hipLaunchKernelGGL(k_fit, dim3(blocks_n), dim3(kBlock), 0, stream, bin, parent_of_node, parent_of_leaf, tri_boxes, sorted_tri, (int)n, node_boxes, node_cost, node_cut, as_leaf, arrived);
-	DB_TRY(hipGetLastError());
+	{
+		// the ready lists live in the collapse queues, which are not in use yet; ctr->queue_out is the tail of the list being written
+		uint32_t *ready[2] = {reinterpret_cast<uint32_t *>(queue[0]), reinterpret_cast<uint32_t *>(queue[1])};
+		DB_TRY(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
+		hipLaunchKernelGGL(k_fit_leaves, dim3(std::min(blocks_n, kStrideBlocks)), dim3(kBlock), 0, stream, parent_of_leaf, (int)n, arrived, ready[0], &ctr->queue_out);
+		int cur = 0;
+		uint32_t settled = 0;
+		for (;;) {
+			unsigned int n_ready = 0;
+			DB_TRY(hipMemcpyAsync(&n_ready, &ctr->queue_out, sizeof(n_ready), hipMemcpyDeviceToHost, stream));
+			DB_TRY(hipStreamSynchronize(stream));
+			if (n_ready == 0) break;
+			settled += n_ready;
+			if (settled > n - 1) { err = "build_bvh_device: the bottom-up pass settled more nodes than the tree has"; return hipErrorUnknown; }
+			DB_TRY(hipMemsetAsync(&ctr->queue_out, 0, sizeof(unsigned int), stream));
+			const unsigned blocks_r = std::min((n_ready + kBlock - 1) / kBlock, kStrideBlocks);
+			hipLaunchKernelGGL(k_fit_round, dim3(blocks_r), dim3(kBlock), 0, stream, bin, parent_of_node, tri_boxes, sorted_tri, ready[cur], n_ready, node_boxes,
+			                   node_cost, node_cut, as_leaf, arrived, ready[cur ^ 1], &ctr->queue_out);
+			cur ^= 1;
+		}
+		DB_TRY(hipGetLastError());
+		if (settled != n - 1) { err = "build_bvh_device: the bottom-up pass did not reach every node"; return hipErrorUnknown; }
+	}
 
 	// ---- collapse, level by level.  A wide node has at least two children, so there are at most n - 1 of them.
 	WideNode *wide = nullptr;
