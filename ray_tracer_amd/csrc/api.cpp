@@ -1,6 +1,9 @@
 // extern "C" layer: argument checks, HIP error mapping, scene upload.  No kernels here.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <algorithm>
@@ -10,6 +13,7 @@
 #include "context.h"
 #include "device_build.h"
 #include "filter.h"
+#include "parallel_for.h"
 #include "trace.h"
 
 using namespace mi355rt;
@@ -114,6 +118,7 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->d_stage_rays) (void)hipFree(ctx->d_stage_rays);
 	if (ctx->d_stage_out) (void)hipFree(ctx->d_stage_out);
 	if (ctx->d_stage_t64) (void)hipFree(ctx->d_stage_t64);
+	ctx->pinned.release();
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -141,7 +146,17 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	ctx->has_materials = false;
 	ctx->render.begun = false;
 	std::string err;
+	// MI355RT_DEBUG: where the time of an upload goes (host tables, tree, shading tables), on stderr
+	const bool timing = std::getenv("MI355RT_DEBUG") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!timing) return;
+		const auto now = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "[mi355rt] rt_upload_mesh: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
 	if (!ctx->host.build(*mesh, err)) return set_err(ctx, RT_ERR_MESH, err);
+	lap("polygon tables");
 	const HostScene &hs = ctx->host;
 	const uint64_t nt = hs.n_tris;
 	int builder = ctx->builder;
@@ -163,18 +178,27 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	std::vector<uint32_t> tri_leaf(nt);
 	if (builder == RT_BUILDER_DEVICE_LBVH) {
 		// records go up in fan order; the device builds the tree and reorders them
-		std::vector<double> tri_a(6 * nt), tri_b(6 * nt);
-		for (uint64_t t = 0; t < nt; t++) fill_halves(&tri_a[6 * t], &tri_b[6 * t], (uint32_t)t);
 		void *d_a = nullptr, *d_b = nullptr;
 		DeviceBvh built;
 		bool ok = dev_upload(ctx, ctx->d_tri_face, hs.tri_face) && dev_upload(ctx, ctx->d_face_object, hs.face_object);
 		const uint64_t bytes_before = ctx->device_bytes;
-		ok = ok && dev_upload(ctx, d_a, tri_a) && dev_upload(ctx, d_b, tri_b);
+		ok = ok && !ctx->fail_hip(hipMalloc(&d_a, 48 * nt), "hipMalloc") && !ctx->fail_hip(hipMalloc(&d_b, 48 * nt), "hipMalloc");
+		for (int half = 0; half < 2 && ok; half++)
+			ok = !ctx->fail_hip(upload_generated(ctx->pinned, half ? d_b : d_a, nt, 48, ctx->stream, [&](size_t t_begin, size_t t_end, char *out) {
+				double other[6];
+				for (size_t t = t_begin; t < t_end; t++) {
+					double *mine = reinterpret_cast<double *>(out) + 6 * (t - t_begin);
+					if (half) fill_halves(other, mine, (uint32_t)t);
+					else fill_halves(mine, other, (uint32_t)t);
+				}
+			}), "upload of the triangle halves");
+		lap("triangle halves");
 		if (ok && build_bvh_device((const double *)d_a, (const double *)d_b, (const uint32_t *)ctx->d_tri_face, (const uint32_t *)ctx->d_face_object,
 		                           (uint32_t)nt, ctx->stream, built, err) != hipSuccess) {
 			ctx->error = err;
 			ok = false;
 		}
+		lap("copy to the device and tree build");
 		if (d_a) (void)hipFree(d_a);
 		if (d_b) (void)hipFree(d_b);
 		ctx->device_bytes = bytes_before; // the fan-order copies are gone again
@@ -222,16 +246,21 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 		}
 		const uint32_t stride = triangle_record_stride(nt);
 		ctx->geom.tri_stride = stride;
-		std::vector<double> recs(2 * (size_t)stride * std::max<uint64_t>(nt, 1), 0.0);
-		for (uint64_t li = 0; li < nt; li++) { // leaf-ordered records
-			const uint32_t t = ctx->wide.tri_index[li];
-			tri_leaf[t] = (uint32_t)li;
-			double *rec = &recs[2 * (size_t)stride * li];
-			fill_halves(rec, rec + 6, t);
-			const uint32_t meta[4] = {t, hs.tri_face[t], hs.face_object[hs.tri_face[t]], 0u};
-			std::memcpy(rec + 12, meta, sizeof(meta));
-		}
-		if (!dev_upload(ctx, ctx->d_nodes, ctx->wide.nodes) || !dev_upload(ctx, ctx->d_tri, recs) ||
+		const size_t rec_bytes = 16 * (size_t)stride;
+		bool recs_ok = !ctx->fail_hip(hipMalloc(&ctx->d_tri, rec_bytes * std::max<uint64_t>(nt, 1)), "hipMalloc");
+		if (recs_ok) ctx->device_bytes += rec_bytes * std::max<uint64_t>(nt, 1);
+		recs_ok = recs_ok && !ctx->fail_hip(upload_generated(ctx->pinned, ctx->d_tri, nt, rec_bytes, ctx->stream, [&](size_t li_begin, size_t li_end, char *out) {
+			for (size_t li = li_begin; li < li_end; li++) { // leaf-ordered records
+				const uint32_t t = ctx->wide.tri_index[li];
+				tri_leaf[t] = (uint32_t)li;
+				double *rec = reinterpret_cast<double *>(out + rec_bytes * (li - li_begin));
+				fill_halves(rec, rec + 6, t);
+				const uint32_t meta[4] = {t, hs.tri_face[t], hs.face_object[hs.tri_face[t]], 0u};
+				std::memcpy(rec + 12, meta, sizeof(meta));
+				if (stride > 7) rec[14] = rec[15] = 0.0;
+			}
+		}), "upload of the triangle records");
+		if (!recs_ok || !dev_upload(ctx, ctx->d_nodes, ctx->wide.nodes) ||
 		    !dev_upload(ctx, ctx->d_leaf_tri, ctx->wide.tri_index) || !dev_upload(ctx, ctx->d_tri_face, hs.tri_face) ||
 		    !dev_upload(ctx, ctx->d_face_object, hs.face_object)) {
 			std::string keep = ctx->error;
@@ -239,6 +268,7 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 			return set_err(ctx, RT_ERR_HIP, keep);
 		}
 	}
+	lap("tree and records in place");
 	ctx->geom.nodes = (const float4 *)ctx->d_nodes;
 	ctx->geom.tri = (const double2 *)ctx->d_tri;
 	ctx->geom.leaf_tri = (const uint32_t *)ctx->d_leaf_tri;
@@ -247,8 +277,9 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	ctx->geom.n_tris = (uint32_t)nt;
 	ctx->geom.depth = ctx->wide.depth;
 	ctx->geom.watertight = ctx->triangle_test == RT_TRIANGLE_WATERTIGHT ? 1u : 0u;
-	hipError_t e = render_upload_scene(ctx->render, hs, tri_leaf, ctx->geom.tri_face, ctx->geom.face_object, ctx->stream, err);
+	hipError_t e = render_upload_scene(ctx->render, hs, tri_leaf, ctx->geom.tri_face, ctx->geom.face_object, ctx->pinned, ctx->stream, err);
 	if (e != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
+	lap("shading tables");
 	ctx->has_mesh = true;
 	return RT_OK;
 }

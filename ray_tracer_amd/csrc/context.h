@@ -9,6 +9,7 @@
 #include "host_scene.h"
 #include "mi355rt.h"
 #include "render.h"
+#include "staged_copy.h"
 
 struct rt_context {
 	int device = 0;
@@ -33,6 +34,7 @@ struct rt_context {
 	// staging for the host-buffer trace entry points (grown on demand)
 	void *d_stage_rays = nullptr, *d_stage_out = nullptr, *d_stage_t64 = nullptr;
 	uint64_t stage_capacity = 0;
+	mi355rt::PinnedPieces pinned; // the scene's large tables are uploaded through these
 
 	std::vector<rt_material> materials;
 	std::vector<uint32_t> light_faces;

@@ -2,7 +2,9 @@
 // device evaluates (face normal, v[0]) carries the same bits as the reference's ConvexPolygon.
 // Compiled with -ffp-contract=off.
 #include "host_scene.h"
+#include "parallel_for.h"
 #include <cmath>
+#include <mutex>
 
 namespace mi355rt {
 
@@ -42,37 +44,47 @@ bool HostScene::build(const rt_mesh &m, std::string &err)
 		if (object_begin[o + 1] < object_begin[o]) { err = "rt_mesh: object_begin not monotone"; return false; }
 		for (uint64_t f = object_begin[o]; f < object_begin[o + 1]; f++) face_object[f] = o;
 	}
-	for (uint64_t f = 0; f < n_faces; f++) {
-		uint64_t b = face_begin[f], e = face_begin[f + 1];
-		for (uint64_t k = b; k < e; k++) { // object.cpp:111-116
-			int64_t iv = m.corners[3 * k], ivt = m.corners[3 * k + 1], ivn = m.corners[3 * k + 2];
-			if (iv < 0 || (uint64_t)iv >= m.n_v || ivn < 0 || (uint64_t)ivn >= m.n_vn || (ivt >= 0 && (uint64_t)ivt >= m.n_vt)) {
-				err = "rt_mesh: corner " + std::to_string(k) + " indexes outside v/vt/vn (every corner needs a vn)";
-				return false;
+	// polygons are independent of each other: the loop is split among host threads; the lowest bad corner is the one reported
+	std::mutex bad_lock;
+	uint64_t bad_corner = UINT64_MAX;
+	parallel_for(n_faces, 1 << 14, [&](uint64_t f_begin, uint64_t f_end) {
+		for (uint64_t f = f_begin; f < f_end; f++) {
+			uint64_t b = face_begin[f], e = face_begin[f + 1];
+			for (uint64_t k = b; k < e; k++) { // object.cpp:111-116
+				int64_t iv = m.corners[3 * k], ivt = m.corners[3 * k + 1], ivn = m.corners[3 * k + 2];
+				if (iv < 0 || (uint64_t)iv >= m.n_v || ivn < 0 || (uint64_t)ivn >= m.n_vn || (ivt >= 0 && (uint64_t)ivt >= m.n_vt)) {
+					std::lock_guard<std::mutex> hold(bad_lock);
+					bad_corner = std::min(bad_corner, k);
+					return;
+				}
+				for (int c = 0; c < 3; c++) pv[3 * k + c] = m.v[3 * iv + c];
+				for (int c = 0; c < 3; c++) pvt[3 * k + c] = ivt >= 0 ? m.vt[3 * ivt + c] : 0.0;
+				d3 n = unit(ld(m.vn + 3 * ivn));
+				pn[3 * k] = n.x; pn[3 * k + 1] = n.y; pn[3 * k + 2] = n.z;
 			}
-			for (int c = 0; c < 3; c++) pv[3 * k + c] = m.v[3 * iv + c];
-			for (int c = 0; c < 3; c++) pvt[3 * k + c] = ivt >= 0 ? m.vt[3 * ivt + c] : 0.0;
-			d3 n = unit(ld(m.vn + 3 * ivn));
-			pn[3 * k] = n.x; pn[3 * k + 1] = n.y; pn[3 * k + 2] = n.z;
+			d3 v0 = ld(&pv[3 * b]), v1 = ld(&pv[3 * (b + 1)]), v2 = ld(&pv[3 * (b + 2)]);
+			d3 fn = unit(cross(sub(v1, v0), sub(v2, v1))); // object.cpp:117-120
+			for (uint64_t k = b; k < e; k++)               // object.cpp:121-126: flip once per disagreeing vertex normal
+				if (dot(fn, ld(&pn[3 * k])) < 0.0) { fn.x *= -1.0; fn.y *= -1.0; fn.z *= -1.0; }
+			face_normal[3 * f] = fn.x; face_normal[3 * f + 1] = fn.y; face_normal[3 * f + 2] = fn.z;
+			// CalcTriangleAreas, object.cpp:375-395
+			double area = 0.0;
+			uint64_t t0 = tri_begin[f], ntf = e - b - 2;
+			for (uint64_t ti = 0; ti < ntf; ti++) {
+				d3 a = sub(ld(&pv[3 * (b + ti + 1)]), v0), bb = sub(ld(&pv[3 * (b + ti + 2)]), v0);
+				double tri_area = len(cross(a, bb)) / 2.0;
+				tri_cum[t0 + ti] = ti == 0 ? tri_area : tri_cum[t0 + ti - 1] + tri_area;
+				tri_face[t0 + ti] = (uint32_t)f;
+				area += tri_area;
+			}
+			for (uint64_t ti = 0; ti < ntf; ti++) tri_cum[t0 + ti] /= area;
+			tri_cum[t0 + ntf - 1] = 1.0;
+			polygon_area[f] = area;
 		}
-		d3 v0 = ld(&pv[3 * b]), v1 = ld(&pv[3 * (b + 1)]), v2 = ld(&pv[3 * (b + 2)]);
-		d3 fn = unit(cross(sub(v1, v0), sub(v2, v1))); // object.cpp:117-120
-		for (uint64_t k = b; k < e; k++)               // object.cpp:121-126: flip once per disagreeing vertex normal
-			if (dot(fn, ld(&pn[3 * k])) < 0.0) { fn.x *= -1.0; fn.y *= -1.0; fn.z *= -1.0; }
-		face_normal[3 * f] = fn.x; face_normal[3 * f + 1] = fn.y; face_normal[3 * f + 2] = fn.z;
-		// CalcTriangleAreas, object.cpp:375-395
-		double area = 0.0;
-		uint64_t t0 = tri_begin[f], ntf = e - b - 2;
-		for (uint64_t ti = 0; ti < ntf; ti++) {
-			d3 a = sub(ld(&pv[3 * (b + ti + 1)]), v0), bb = sub(ld(&pv[3 * (b + ti + 2)]), v0);
-			double tri_area = len(cross(a, bb)) / 2.0;
-			tri_cum[t0 + ti] = ti == 0 ? tri_area : tri_cum[t0 + ti - 1] + tri_area;
-			tri_face[t0 + ti] = (uint32_t)f;
-			area += tri_area;
-		}
-		for (uint64_t ti = 0; ti < ntf; ti++) tri_cum[t0 + ti] /= area;
-		tri_cum[t0 + ntf - 1] = 1.0;
-		polygon_area[f] = area;
+	});
+	if (bad_corner != UINT64_MAX) {
+		err = "rt_mesh: corner " + std::to_string(bad_corner) + " indexes outside v/vt/vn (every corner needs a vn)";
+		return false;
 	}
 	return true;
 }

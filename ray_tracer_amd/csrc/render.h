@@ -7,6 +7,7 @@
 #include "device_scene.h"
 #include "host_scene.h"
 #include "mi355rt.h"
+#include "staged_copy.h"
 
 namespace mi355rt {
 
@@ -88,7 +89,7 @@ struct RenderState {
 // upload of shading data: per-triangle float attributes, materials, lights, camera/band tables
 // tri_leaf: fan triangle -> leaf-order index; d_tri_face / d_face_object: the geometry's device tables
 hipError_t render_upload_scene(RenderState &rs, const HostScene &host, const std::vector<uint32_t> &tri_leaf,
-                               const uint32_t *d_tri_face, const uint32_t *d_face_object, hipStream_t stream, std::string &err);
+                               const uint32_t *d_tri_face, const uint32_t *d_face_object, PinnedPieces &pinned, hipStream_t stream, std::string &err);
 // per-hit material programs for slot a of some objects (validated by the caller); nullptr or no programs removes them
 hipError_t render_upload_material_graphs(RenderState &rs, const rt_material_graphs *g, hipStream_t stream, std::string &err);
 // environment texture of the naive integrator (renderer.cpp:175-193); texels == nullptr removes it

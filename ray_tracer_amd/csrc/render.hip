@@ -19,10 +19,12 @@
 #include <cstring>
 #include <algorithm>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <thread>
 #include <vector>
+#include "parallel_for.h"
 #include "render.h"
 #include "trace.h"
 
@@ -1281,36 +1283,46 @@ void free_queues(Impl &im)
 
 // fan triangle -> leaf order is filled by the caller through this hook (geometry upload knows the BVH)
 hipError_t render_upload_scene(RenderState &rs, const HostScene &host, const std::vector<uint32_t> &tri_leaf,
-                               const uint32_t *d_tri_face, const uint32_t *d_face_object, hipStream_t stream, std::string &err)
+                               const uint32_t *d_tri_face, const uint32_t *d_face_object, PinnedPieces &pinned, hipStream_t stream, std::string &err)
 {
 	Impl &im = *impl_of(rs);
-	std::vector<float4> ts(6 * host.n_tris);
-	for (uint64_t t = 0; t < host.n_tris; t++) {
-		const uint32_t f = host.tri_face[t];
-		const uint64_t b = host.face_begin[f], k = t - host.tri_begin[f];
-		const double *v0 = &host.pv[3 * b], *v1 = &host.pv[3 * (b + k + 1)], *v2 = &host.pv[3 * (b + k + 2)];
-		const double *n0 = &host.pn[3 * b], *n1 = &host.pn[3 * (b + k + 1)], *n2 = &host.pn[3 * (b + k + 2)];
-		const double *fn = &host.face_normal[3 * f];
-		// tri_area of HitTriangle (object.cpp:249): |cross(v1 - v0, v2 - v1)|
-		double ax = v1[0] - v0[0], ay = v1[1] - v0[1], az = v1[2] - v0[2], bx = v2[0] - v1[0], by = v2[1] - v1[1], bz = v2[2] - v1[2];
-		double cx = ay * bz - az * by, cy = -(ax * bz - az * bx), cz = ax * by - ay * bx;
-		double area2 = std::sqrt(cx * cx + cy * cy + cz * cz);
-		float4 *o = &ts[6 * t];
-		o[0] = make_float4((float)v0[0], (float)v0[1], (float)v0[2], (float)v1[0]);
-		o[1] = make_float4((float)v1[1], (float)v1[2], (float)v2[0], (float)v2[1]);
-		o[2] = make_float4((float)v2[2], (float)n0[0], (float)n0[1], (float)n0[2]);
-		o[3] = make_float4((float)n1[0], (float)n1[1], (float)n1[2], (float)n2[0]);
-		o[4] = make_float4((float)n2[1], (float)n2[2], (float)fn[0], (float)fn[1]);
-		o[5] = make_float4((float)fn[2], (float)area2, 0.0f, 0.0f);
-	}
+	if (im.tri_shade) { (void)hipFree(im.tri_shade); im.tri_shade = nullptr; }
+	HIP_TRY(hipMalloc((void **)&im.tri_shade, 96 * std::max<uint64_t>(host.n_tris, 1)));
+	HIP_TRY(upload_generated(pinned, im.tri_shade, host.n_tris, 96, stream, [&](size_t t_begin, size_t t_end, char *out) {
+		for (size_t t = t_begin; t < t_end; t++) {
+			const uint32_t f = host.tri_face[t];
+			const uint64_t b = host.face_begin[f], k = t - host.tri_begin[f];
+			const double *v0 = &host.pv[3 * b], *v1 = &host.pv[3 * (b + k + 1)], *v2 = &host.pv[3 * (b + k + 2)];
+			const double *n0 = &host.pn[3 * b], *n1 = &host.pn[3 * (b + k + 1)], *n2 = &host.pn[3 * (b + k + 2)];
+			const double *fn = &host.face_normal[3 * f];
+			// tri_area of HitTriangle (object.cpp:249): |cross(v1 - v0, v2 - v1)|
+			double ax = v1[0] - v0[0], ay = v1[1] - v0[1], az = v1[2] - v0[2], bx = v2[0] - v1[0], by = v2[1] - v1[1], bz = v2[2] - v1[2];
+			double cx = ay * bz - az * by, cy = -(ax * bz - az * bx), cz = ax * by - ay * bx;
+			double area2 = std::sqrt(cx * cx + cy * cy + cz * cz);
+			float4 *o = reinterpret_cast<float4 *>(out) + 6 * (t - t_begin);
+			o[0] = make_float4((float)v0[0], (float)v0[1], (float)v0[2], (float)v1[0]);
+			o[1] = make_float4((float)v1[1], (float)v1[2], (float)v2[0], (float)v2[1]);
+			o[2] = make_float4((float)v2[2], (float)n0[0], (float)n0[1], (float)n0[2]);
+			o[3] = make_float4((float)n1[0], (float)n1[1], (float)n1[2], (float)n2[0]);
+			o[4] = make_float4((float)n2[1], (float)n2[2], (float)fn[0], (float)fn[1]);
+			o[5] = make_float4((float)fn[2], (float)area2, 0.0f, 0.0f);
+		}
+	}));
 	{ // the scene's bounding box for k_generate's camera-ray test
 		double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX}, big = 0.0;
-		for (size_t c = 0; c + 2 < host.pv.size(); c += 3)
-			for (int a = 0; a < 3; a++) {
-				lo[a] = std::min(lo[a], host.pv[c + a]);
-				hi[a] = std::max(hi[a], host.pv[c + a]);
-				big = std::max(big, std::fabs(host.pv[c + a]));
-			}
+		std::mutex merge;
+		parallel_for(host.pv.size() / 3, 1 << 16, [&](uint64_t c_begin, uint64_t c_end) {
+			double plo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, phi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX}, pbig = 0.0;
+			for (uint64_t c = 3 * c_begin; c < 3 * c_end; c += 3)
+				for (int a = 0; a < 3; a++) {
+					plo[a] = std::min(plo[a], host.pv[c + a]);
+					phi[a] = std::max(phi[a], host.pv[c + a]);
+					pbig = std::max(pbig, std::fabs(host.pv[c + a]));
+				}
+			std::lock_guard<std::mutex> hold(merge);
+			for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], plo[a]); hi[a] = std::max(hi[a], phi[a]); }
+			big = std::max(big, pbig);
+		});
 		im.scene_lo = make_float4(std::nextafter((float)lo[0], -FLT_MAX), std::nextafter((float)lo[1], -FLT_MAX), std::nextafter((float)lo[2], -FLT_MAX),
 		                          std::nextafter((float)big, FLT_MAX));
 		im.scene_hi = make_float4(std::nextafter((float)hi[0], FLT_MAX), std::nextafter((float)hi[1], FLT_MAX), std::nextafter((float)hi[2], FLT_MAX), 0.0f);
@@ -1320,7 +1332,6 @@ hipError_t render_upload_scene(RenderState &rs, const HostScene &host, const std
 	std::vector<float> fa(host.n_faces), tc(host.n_tris);
 	for (uint64_t f = 0; f < host.n_faces; f++) fa[f] = (float)host.polygon_area[f];
 	for (uint64_t t = 0; t < host.n_tris; t++) tc[t] = (float)host.tri_cum[t];
-	HIP_TRY(upload(im.tri_shade, ts, stream));
 	// texture coordinates of the fan triangles' corners, only when the mesh has any (read by per-hit material graphs)
 	bool any_vt = false;
 	for (double x : host.pvt) if (x != 0.0) { any_vt = true; break; }
