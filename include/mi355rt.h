@@ -29,7 +29,8 @@ typedef enum rt_status {
 	RT_ERR_NO_DEVICE = -3,  /* no HIP device: there is no CPU fallback */
 	RT_ERR_NO_LIGHTS = -4,  /* Renderer::LoadMaterials returns false when no object is a light (renderer.cpp:41-42) */
 	RT_ERR_NO_MATERIAL = -5,/* Renderer::LoadMaterials returns false when an object has no material (renderer.cpp:29-32) */
-	RT_ERR_MESH = -6        /* malformed mesh (index out of range, face with < 3 corners, missing vn) */
+	RT_ERR_MESH = -6,       /* malformed mesh (index out of range, face with < 3 corners, missing vn) */
+	RT_ERR_HOST = -7        /* the host side ran out of memory or could not start a thread; text in rt_last_error */
 } rt_status;
 
 typedef struct rt_context rt_context;

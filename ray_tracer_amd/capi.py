@@ -6,7 +6,7 @@ import numpy as np
 
 NBINS = 30
 MISS = 0xFFFFFFFF
-OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NO_LIGHTS, ERR_NO_MATERIAL, ERR_MESH = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NO_LIGHTS, ERR_NO_MATERIAL, ERR_MESH, ERR_HOST = 0, -1, -2, -3, -4, -5, -6, -7
 BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH, BUILDER_AUTO = 0, 1, 2
 MAT_NONE, MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_COLORED_METAL, MAT_GGX = range(7)
 ALG_NAIVE, ALG_NEE, ALG_MIS, ALG_NAIVE_BDPT, ALG_MIS_BDPT = 0, 1, 2, 3, 4

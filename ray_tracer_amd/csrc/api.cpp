@@ -28,6 +28,18 @@ int set_err(rt_context *ctx, int code, const std::string &msg)
 	return code;
 }
 
+// No exception leaves the library (the callers are C, ctypes, cgo-style bindings): what the host side can throw -- std::bad_alloc
+// from a table of a large scene, std::system_error from a thread that could not be started -- ends the call with RT_ERR_HOST and
+// its text in rt_last_error.  Every exported function with a body worth the name is a function-try-block ending in one of these.
+int caught(rt_context *ctx, const char *what) noexcept
+{
+	try { return set_err(ctx, RT_ERR_HOST, std::string("host side: ") + what); } catch (...) { return RT_ERR_HOST; }
+}
+int caught_group(rt_group *g, const char *what) noexcept;
+#define RT_CATCH(ctx) catch (const std::exception &e_) { return caught(ctx, e_.what()); } catch (...) { return caught(ctx, "unknown exception"); }
+#define RT_CATCH_GROUP(g) catch (const std::exception &e_) { return caught_group(g, e_.what()); } catch (...) { return caught_group(g, "unknown exception"); }
+#define RT_CATCH_CREATE catch (const std::exception &e_) { return caught(nullptr, e_.what()); } catch (...) { return caught(nullptr, "unknown exception"); }
+
 template <class T>
 bool dev_upload(rt_context *ctx, void *&dst, const std::vector<T> &src)
 {
@@ -78,7 +90,7 @@ void rt_context::free_geometry()
 extern "C" {
 
 int rt_create(int device, rt_context **out)
-{
+try {
 	if (!out) return set_err(nullptr, RT_ERR_INVALID, "rt_create: out is NULL");
 	*out = nullptr;
 	int count = 0;
@@ -105,7 +117,7 @@ int rt_create(int device, rt_context **out)
 	}
 	*out = ctx;
 	return RT_OK;
-}
+} RT_CATCH_CREATE
 
 void rt_destroy(rt_context *ctx)
 {
@@ -136,7 +148,7 @@ static int finish_pending_paths(rt_context *ctx)
 }
 
 int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
-{
+try {
 	if (!ctx || !mesh) return set_err(ctx, RT_ERR_INVALID, "rt_upload_mesh: NULL argument");
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	if (int rc = finish_pending_paths(ctx)) return rc;
@@ -282,18 +294,18 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh)
 	lap("shading tables");
 	ctx->has_mesh = true;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_set_builder(rt_context *ctx, int builder)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (builder != RT_BUILDER_HOST_SAH && builder != RT_BUILDER_DEVICE_LBVH && builder != RT_BUILDER_AUTO) return set_err(ctx, RT_ERR_INVALID, "rt_set_builder: unknown builder");
 	ctx->builder = builder;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_set_triangle_test(rt_context *ctx, int mode)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (mode != RT_TRIANGLE_REFERENCE && mode != RT_TRIANGLE_WATERTIGHT) return set_err(ctx, RT_ERR_INVALID, "rt_set_triangle_test: unknown mode");
 	if (!use_device(ctx)) return RT_ERR_HIP;
@@ -301,10 +313,10 @@ int rt_set_triangle_test(rt_context *ctx, int mode)
 	ctx->triangle_test = mode;
 	ctx->geom.watertight = mode == RT_TRIANGLE_WATERTIGHT ? 1u : 0u;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_upload_materials(rt_context *ctx, const rt_material *per_object, uint32_t n_objects)
-{
+try {
 	if (!ctx || !per_object) return set_err(ctx, RT_ERR_INVALID, "rt_upload_materials: NULL argument");
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_upload_materials: no mesh uploaded");
 	if (n_objects != ctx->host.n_objects) return set_err(ctx, RT_ERR_NO_MATERIAL, "rt_upload_materials: one record per obj object is required");
@@ -328,10 +340,10 @@ int rt_upload_materials(rt_context *ctx, const rt_material *per_object, uint32_t
 		return set_err(ctx, RT_ERR_HIP, err);
 	ctx->has_materials = true;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_upload_material_graphs(rt_context *ctx, const rt_material_graphs *g)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!ctx->has_materials) return set_err(ctx, RT_ERR_INVALID, "rt_upload_material_graphs: upload the material records first");
 	if (!use_device(ctx)) return RT_ERR_HIP;
@@ -398,10 +410,10 @@ int rt_upload_material_graphs(rt_context *ctx, const rt_material_graphs *g)
 	std::string err;
 	if (render_upload_material_graphs(ctx->render, g, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_set_environment(rt_context *ctx, const uint8_t *texels, int width, int height, int bpp, double brightness)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (texels && (width <= 0 || height <= 0 || bpp < 3 || bpp > 4)) return set_err(ctx, RT_ERR_INVALID, "rt_set_environment: needs width, height > 0 and 3 or 4 bytes per texel");
 	if (!use_device(ctx)) return RT_ERR_HIP;
@@ -409,18 +421,18 @@ int rt_set_environment(rt_context *ctx, const uint8_t *texels, int width, int he
 	std::string err;
 	if (render_set_environment(ctx->render, texels, width, height, bpp, brightness, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_set_camera(rt_context *ctx, const rt_camera *cam)
-{
+try {
 	if (!ctx || !cam) return set_err(ctx, RT_ERR_INVALID, "rt_set_camera: NULL argument");
 	ctx->camera = *cam;
 	ctx->has_camera = true;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_clear(rt_context *ctx)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	if (int rc = finish_pending_paths(ctx)) return rc;
@@ -432,10 +444,10 @@ int rt_clear(rt_context *ctx)
 	ctx->bvh = Bvh2();
 	ctx->wide = BvhWide();
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream)
-{
+try {
 	if (!ctx || (n && (!d_rays || !d_hits))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_device: NULL argument");
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_device: no mesh uploaded");
 	if (n >= (1ull << 32) * 256ull) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_device: too many rays for one launch");
@@ -446,10 +458,10 @@ int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, voi
 	ctx->profiler.end(s);
 	if (ctx->fail_hip(e, "closest-hit launch")) return RT_ERR_HIP;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_out, void *stream)
-{
+try {
 	if (!ctx || (n && (!d_rays || !d_out))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any_device: NULL argument");
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any_device: no mesh uploaded");
 	if (!use_device(ctx)) return RT_ERR_HIP;
@@ -459,10 +471,10 @@ int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d
 	ctx->profiler.end(s);
 	if (ctx->fail_hip(e, "any-hit launch")) return RT_ERR_HIP;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_trace_closest(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64)
-{
+try {
 	if (!ctx || (n && (!rays || !hits))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest: NULL argument");
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest: no mesh uploaded");
 	if (n == 0) return RT_OK;
@@ -474,10 +486,10 @@ int rt_trace_closest(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hi
 	if (t64 && ctx->fail_hip(hipMemcpyAsync(t64, ctx->d_stage_t64, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "D2H t64")) return RT_ERR_HIP;
 	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "closest-hit kernel")) return RT_ERR_HIP;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_trace_closest_static(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64)
-{
+try {
 	if (!ctx || (n && (!rays || !hits))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_static: NULL argument");
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_static: no mesh uploaded");
 	if (n > kStaticRays)
@@ -495,10 +507,10 @@ int rt_trace_closest_static(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_
 	if (t64 && ctx->fail_hip(hipMemcpyAsync(t64, st.t64, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "D2H t64")) return RT_ERR_HIP;
 	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "closest-hit kernel")) return RT_ERR_HIP;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_trace_any(rt_context *ctx, const rt_ray *rays, uint64_t n, uint8_t *out)
-{
+try {
 	if (!ctx || (n && (!rays || !out))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any: NULL argument");
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any: no mesh uploaded");
 	if (n == 0) return RT_OK;
@@ -509,10 +521,10 @@ int rt_trace_any(rt_context *ctx, const rt_ray *rays, uint64_t n, uint8_t *out)
 	if (ctx->fail_hip(hipMemcpyAsync(out, ctx->d_stage_out, n, hipMemcpyDeviceToHost, ctx->stream), "D2H any")) return RT_ERR_HIP;
 	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "any-hit kernel")) return RT_ERR_HIP;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_render_begin(rt_context *ctx, int nx, int ny, int ns, int spectral_samples, int algorithm, uint64_t seed, void *d_film)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!ctx->has_mesh || !ctx->has_materials || !ctx->has_camera)
 		return set_err(ctx, RT_ERR_INVALID, "rt_render_begin: mesh, materials and camera must be set first");
@@ -525,10 +537,10 @@ int rt_render_begin(rt_context *ctx, int nx, int ny, int ns, int spectral_sample
 	hipError_t e = render_begin(ctx->render, ctx->camera, nx, ny, ns, spectral_samples, algorithm, seed, d_film, ctx->stream, err);
 	if (e != hipSuccess) return set_err(ctx, e == hipErrorInvalidValue ? RT_ERR_INVALID : RT_ERR_HIP, err);
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_render_pass(rt_context *ctx, int first_sample, int n_samples)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_render_pass: call rt_render_begin first");
 	// the tables the kernels index (tree, triangles, materials, lights) must be the ones rt_render_begin saw
@@ -539,19 +551,19 @@ int rt_render_pass(rt_context *ctx, int first_sample, int n_samples)
 	std::string err;
 	if (render_pass(ctx->render, ctx->geom, first_sample, n_samples, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_render_sync(rt_context *ctx)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	if (int rc = finish_pending_paths(ctx)) return rc;
 	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "render kernels")) return RT_ERR_HIP;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_download_film(rt_context *ctx, double *spectrum_img)
-{
+try {
 	if (!ctx || !spectrum_img) return set_err(ctx, RT_ERR_INVALID, "rt_download_film: NULL argument");
 	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_download_film: nothing rendered");
 	if (!use_device(ctx)) return RT_ERR_HIP;
@@ -559,10 +571,10 @@ int rt_download_film(rt_context *ctx, double *spectrum_img)
 	std::string err;
 	if (render_download_film(ctx->render, spectrum_img, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_download_preview(rt_context *ctx, int samples_done, double *preview_img)
-{
+try {
 	if (!ctx || !preview_img) return set_err(ctx, RT_ERR_INVALID, "rt_download_preview: NULL argument");
 	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_download_preview: nothing rendered");
 	if (!use_device(ctx)) return RT_ERR_HIP;
@@ -570,19 +582,19 @@ int rt_download_preview(rt_context *ctx, int samples_done, double *preview_img)
 	std::string err;
 	if (render_download_preview(ctx->render, samples_done, preview_img, ctx->stream, err) != hipSuccess) return set_err(ctx, RT_ERR_HIP, err);
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_film_device_ptr(rt_context *ctx, void **d_film, size_t *bytes)
-{
+try {
 	if (!ctx || !d_film) return RT_ERR_INVALID;
 	if (!ctx->render.begun) return set_err(ctx, RT_ERR_INVALID, "rt_film_device_ptr: call rt_render_begin first");
 	*d_film = ctx->render.d_film;
 	if (bytes) *bytes = (size_t)ctx->render.nx * ctx->render.ny * RT_NBINS * sizeof(float);
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_get_stats(rt_context *ctx, rt_stats *out)
-{
+try {
 	if (!ctx || !out) return RT_ERR_INVALID;
 	if (ctx->render.begun && use_device(ctx)) { if (int rc = finish_pending_paths(ctx)) return rc; }
 	std::memset(out, 0, sizeof(*out));
@@ -599,10 +611,10 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
 	out->camera_samples = ctx->render.camera_samples;
 	out->device_bytes = ctx->device_bytes;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_get_bvh2(rt_context *ctx, rt_bvh2_node *nodes, uint64_t *n_nodes, uint32_t *tri_index, uint64_t *n_tris)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_get_bvh2: no mesh uploaded");
 	if (ctx->built_on_device) return set_err(ctx, RT_ERR_INVALID, "rt_get_bvh2: the tree was built on the device; only the host builder keeps a BVH2");
@@ -611,10 +623,10 @@ int rt_get_bvh2(rt_context *ctx, rt_bvh2_node *nodes, uint64_t *n_nodes, uint32_
 	if (nodes) std::memcpy(nodes, ctx->bvh.nodes.data(), ctx->bvh.nodes.size() * sizeof(rt_bvh2_node));
 	if (tri_index) std::memcpy(tri_index, ctx->bvh.tri_index.data(), ctx->bvh.tri_index.size() * sizeof(uint32_t));
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_get_wide_bvh(rt_context *ctx, rt_wide_node *nodes, uint64_t *n_nodes, uint32_t *tri_index, uint64_t *n_tris)
-{
+try {
 	static_assert(sizeof(rt_wide_node) == sizeof(WideNode), "the public record is the device record");
 	if (!ctx) return RT_ERR_INVALID;
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_get_wide_bvh: no mesh uploaded");
@@ -626,20 +638,20 @@ int rt_get_wide_bvh(rt_context *ctx, rt_wide_node *nodes, uint64_t *n_nodes, uin
 	}
 	if (tri_index) std::memcpy(tri_index, ctx->wide.tri_index.data(), ctx->wide.tri_index.size() * sizeof(uint32_t));
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_filter_bilateral_device(rt_context *ctx, const void *d_rgba, int width, int height, int window, double sigma_d, double sigma_r, void *d_out)
-{
+try {
 	if (!ctx || !d_rgba || !d_out) return set_err(ctx, RT_ERR_INVALID, "rt_filter_bilateral: NULL argument");
 	if (width <= 0 || height <= 0 || window < 0 || window > 64) return set_err(ctx, RT_ERR_INVALID, "rt_filter_bilateral: needs width, height > 0 and 0 <= window <= 64");
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	hipError_t e = launch_bilateral((const double *)d_rgba, width, height, window, sigma_d, sigma_r, (double *)d_out, ctx->stream);
 	if (ctx->fail_hip(e, "k_bilateral")) return RT_ERR_HIP;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_filter_bilateral(rt_context *ctx, const double *rgba, int width, int height, int window, double sigma_d, double sigma_r, double *out)
-{
+try {
 	if (!ctx || !rgba || !out) return set_err(ctx, RT_ERR_INVALID, "rt_filter_bilateral: NULL argument");
 	if (width <= 0 || height <= 0) return set_err(ctx, RT_ERR_INVALID, "rt_filter_bilateral: needs width, height > 0");
 	if (!use_device(ctx)) return RT_ERR_HIP;
@@ -656,7 +668,7 @@ int rt_filter_bilateral(rt_context *ctx, const double *rgba, int width, int heig
 	if (d_in) (void)hipFree(d_in);
 	if (d_out) (void)hipFree(d_out);
 	return rc;
-}
+} RT_CATCH(ctx)
 
 void *rt_stream(rt_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
@@ -671,6 +683,16 @@ struct rt_group {
 };
 
 namespace {
+int caught_group(rt_group *g, const char *what) noexcept
+{
+	try {
+		if (g) g->error = std::string("host side: ") + what;
+		else g_create_error = std::string("host side: ") + what;
+	} catch (...) {
+	}
+	return RT_ERR_HOST;
+}
+
 // runs f(member index) for every member on a thread of its own (a member's calls block on its GPU) and returns the first failure
 template <class F>
 int for_each_member(rt_group *g, F f)
@@ -739,7 +761,7 @@ int group_sum_films(rt_group *g)
 extern "C" {
 
 int rt_group_create(const int *devices, int n, rt_group **out)
-{
+try {
 	if (!out) return set_err(nullptr, RT_ERR_INVALID, "rt_group_create: out is NULL");
 	*out = nullptr;
 	if (!devices || n <= 0 || n > 64) return set_err(nullptr, RT_ERR_INVALID, "rt_group_create: needs 1..64 device ordinals");
@@ -756,7 +778,7 @@ int rt_group_create(const int *devices, int n, rt_group **out)
 	}
 	*out = g;
 	return RT_OK;
-}
+} RT_CATCH_CREATE
 
 void rt_group_destroy(rt_group *g)
 {
@@ -775,48 +797,48 @@ int rt_group_size(const rt_group *g) { return g ? (int)g->members.size() : 0; }
 rt_context *rt_group_context(rt_group *g, int i) { return (g && i >= 0 && (size_t)i < g->members.size()) ? g->members[i] : nullptr; }
 
 int rt_group_upload_mesh(rt_group *g, const rt_mesh *mesh)
-{
+try {
 	if (!g) return RT_ERR_INVALID;
 	return for_each_member(g, [&](size_t i) { return rt_upload_mesh(g->members[i], mesh); });
-}
+} RT_CATCH_GROUP(g)
 int rt_group_upload_materials(rt_group *g, const rt_material *per_object, uint32_t n_objects)
-{
+try {
 	if (!g) return RT_ERR_INVALID;
 	return for_each_member(g, [&](size_t i) { return rt_upload_materials(g->members[i], per_object, n_objects); });
-}
+} RT_CATCH_GROUP(g)
 int rt_group_upload_material_graphs(rt_group *g, const rt_material_graphs *graphs)
-{
+try {
 	if (!g) return RT_ERR_INVALID;
 	return for_each_member(g, [&](size_t i) { return rt_upload_material_graphs(g->members[i], graphs); });
-}
+} RT_CATCH_GROUP(g)
 int rt_group_set_environment(rt_group *g, const uint8_t *texels, int width, int height, int bpp, double brightness)
-{
+try {
 	if (!g) return RT_ERR_INVALID;
 	return for_each_member(g, [&](size_t i) { return rt_set_environment(g->members[i], texels, width, height, bpp, brightness); });
-}
+} RT_CATCH_GROUP(g)
 int rt_group_set_camera(rt_group *g, const rt_camera *cam)
-{
+try {
 	if (!g) return RT_ERR_INVALID;
 	return for_each_member(g, [&](size_t i) { return rt_set_camera(g->members[i], cam); });
-}
+} RT_CATCH_GROUP(g)
 int rt_group_set_triangle_test(rt_group *g, int mode)
-{
+try {
 	if (!g) return RT_ERR_INVALID;
 	return for_each_member(g, [&](size_t i) { return rt_set_triangle_test(g->members[i], mode); });
-}
+} RT_CATCH_GROUP(g)
 int rt_group_clear(rt_group *g)
-{
+try {
 	if (!g) return RT_ERR_INVALID;
 	return for_each_member(g, [&](size_t i) { return rt_clear(g->members[i]); });
-}
+} RT_CATCH_GROUP(g)
 int rt_group_render_begin(rt_group *g, int nx, int ny, int ns, int spectral_samples, int algorithm, uint64_t seed)
-{
+try {
 	if (!g) return RT_ERR_INVALID;
 	// every member gets the whole render's ns (the film weight is 1 / ns per sample) and the same seed: streams are keyed by (pixel, sample)
 	return for_each_member(g, [&](size_t i) { return rt_render_begin(g->members[i], nx, ny, ns, spectral_samples, algorithm, seed, nullptr); });
-}
+} RT_CATCH_GROUP(g)
 int rt_group_render_pass(rt_group *g, int first_sample, int n_samples)
-{
+try {
 	if (!g) return RT_ERR_INVALID;
 	if (first_sample < 0 || n_samples < 0) return group_fail(g, RT_ERR_INVALID, "rt_group_render_pass: negative sample range");
 	const int n = (int)g->members.size();
@@ -825,14 +847,14 @@ int rt_group_render_pass(rt_group *g, int first_sample, int n_samples)
 		member_samples((int)i, n, first_sample, n_samples, f, c);
 		return rt_render_pass(g->members[i], f, c);
 	});
-}
+} RT_CATCH_GROUP(g)
 int rt_group_render_sync(rt_group *g)
-{
+try {
 	if (!g) return RT_ERR_INVALID;
 	return for_each_member(g, [&](size_t i) { return rt_render_sync(g->members[i]); });
-}
+} RT_CATCH_GROUP(g)
 int rt_group_download_film(rt_group *g, double *spectrum_img)
-{
+try {
 	if (!g || !spectrum_img) return RT_ERR_INVALID;
 	if (int rc = rt_group_render_sync(g)) return rc;
 	if (int rc = group_sum_films(g)) return rc;
@@ -840,9 +862,9 @@ int rt_group_download_film(rt_group *g, double *spectrum_img)
 	std::string err;
 	if (render_download_film(root->render, spectrum_img, root->stream, err, g->d_sum) != hipSuccess) return group_fail(g, RT_ERR_HIP, err);
 	return RT_OK;
-}
+} RT_CATCH_GROUP(g)
 int rt_group_download_preview(rt_group *g, int samples_done, double *preview_img)
-{
+try {
 	if (!g || !preview_img) return RT_ERR_INVALID;
 	if (int rc = rt_group_render_sync(g)) return rc;
 	if (int rc = group_sum_films(g)) return rc;
@@ -850,29 +872,29 @@ int rt_group_download_preview(rt_group *g, int samples_done, double *preview_img
 	std::string err;
 	if (render_download_preview(root->render, samples_done, preview_img, root->stream, err, g->d_sum) != hipSuccess) return group_fail(g, RT_ERR_HIP, err);
 	return RT_OK;
-}
+} RT_CATCH_GROUP(g)
 
 int rt_profile_start(rt_context *ctx)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	ctx->profiler.clear();
 	ctx->profiler.enabled = true;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_profile_stop(rt_context *ctx, rt_profile *out)
-{
+try {
 	if (!ctx || !out) return RT_ERR_INVALID;
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	if (int rc = finish_pending_paths(ctx)) return rc;
 	ctx->profiler.enabled = false;
 	ctx->profiler.collect(*out);
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 int rt_render_capture_rays(rt_context *ctx, rt_ray *buf, uint64_t capacity, uint64_t *n_captured)
-{
+try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (ctx->render.begun && use_device(ctx)) { if (int rc = finish_pending_paths(ctx)) return rc; }
 	ctx->render.capture_buf = buf;
@@ -881,6 +903,6 @@ int rt_render_capture_rays(rt_context *ctx, rt_ray *buf, uint64_t capacity, uint
 	ctx->render.capture_count_out = buf ? n_captured : nullptr;
 	if (n_captured) *n_captured = 0;
 	return RT_OK;
-}
+} RT_CATCH(ctx)
 
 } // extern "C"
