@@ -6,6 +6,9 @@
 //          [--devices 0,1,2,3]     render on several GPUs (ordinals may repeat), samples of each pass split between them
 //   rt_cli --ply mesh.ply --dump-ply out.bin       host only: the parsed tables (u64 nv, nf, ni, has_normals; f64 [nv][6];
 //                                                  u64 [nf+1]; i32 [ni]) for tests
+//   rt_cli --obj scene.obj --dump-obj out.txt      host only: what the OBJ parser made of the file, as text ("ok 0|1", then mtl / v /
+//                                                  vt / vn lines with hexadecimal floats, then per object "o [name] [material] s" and
+//                                                  its faces "f v/vt/vn ..." 0-based, -1 absent) for tests
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,7 +20,7 @@ using namespace mi355host;
 
 int main(int argc, char **argv)
 {
-	std::string objp, matp, mapp, film_out, ppm_out, rec_out, graphs_out, alg = "mis", plyp, ply_object = "ply", ply_normals = "auto", ply_dump, devices;
+	std::string objp, matp, mapp, film_out, ppm_out, rec_out, graphs_out, alg = "mis", plyp, ply_object = "ply", ply_normals = "auto", ply_dump, obj_dump, devices;
 	int w = 64, h = 64, ns = 4, spectral = 30;
 	unsigned long long seed = 1;
 	for (int i = 1; i + 1 < argc; i += 2) {
@@ -28,7 +31,7 @@ int main(int argc, char **argv)
 		else if (k == "--seed") seed = std::strtoull(v.c_str(), nullptr, 10); else if (k == "--spectral") spectral = std::atoi(v.c_str());
 		else if (k == "--film") film_out = v; else if (k == "--ppm") ppm_out = v; else if (k == "--records") rec_out = v; else if (k == "--graphs") graphs_out = v;
 		else if (k == "--ply") plyp = v; else if (k == "--ply-object") ply_object = v; else if (k == "--ply-normals") ply_normals = v;
-		else if (k == "--dump-ply") ply_dump = v; else if (k == "--devices") devices = v;
+		else if (k == "--dump-ply") ply_dump = v; else if (k == "--dump-obj") obj_dump = v; else if (k == "--devices") devices = v;
 		else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
 	}
 	if (!ply_dump.empty()) {
@@ -41,6 +44,27 @@ int main(int argc, char **argv)
 		f.write((const char *)p.face_begin.data(), sizeof(uint64_t) * p.face_begin.size());
 		f.write((const char *)p.face_index.data(), sizeof(int32_t) * p.face_index.size());
 		for (auto &e : p.elements) std::printf("element %s %zu %zu\n", e.name.c_str(), e.num_of_elements, e.num_of_property);
+		return 0;
+	}
+	if (!obj_dump.empty()) {
+		obj o;
+		const bool ok = o.Load(objp.c_str());
+		std::FILE *f = std::fopen(obj_dump.c_str(), "w");
+		if (!f) { std::fprintf(stderr, "cannot write %s\n", obj_dump.c_str()); return 7; }
+		std::fprintf(f, "ok %d\n", ok ? 1 : 0);
+		for (auto &m : o.mtl_file) std::fprintf(f, "mtl [%s]\n", m.c_str());
+		for (auto &p : o.v) std::fprintf(f, "v %a %a %a\n", p.e[0], p.e[1], p.e[2]);
+		for (auto &p : o.vt) std::fprintf(f, "vt %a %a %a\n", p.e[0], p.e[1], p.e[2]);
+		for (auto &p : o.vn) std::fprintf(f, "vn %a %a %a\n", p.e[0], p.e[1], p.e[2]);
+		for (auto *ob : o.objects) {
+			std::fprintf(f, "o [%s] [%s] %d\n", ob->name.c_str(), ob->material_name.c_str(), ob->s ? 1 : 0);
+			for (auto &face : ob->faces) {
+				std::fprintf(f, "f");
+				for (auto &c : face) std::fprintf(f, " %lld/%lld/%lld", (long long)c[0], (long long)c[1], (long long)c[2]);
+				std::fprintf(f, "\n");
+			}
+		}
+		std::fclose(f);
 		return 0;
 	}
 	if (objp.empty() || matp.empty() || mapp.empty()) { std::fprintf(stderr, "need --obj --materials --objmatmap\n"); return 2; }

@@ -372,3 +372,71 @@ def test_cpp_host_compiles_noise_graphs_like_the_python_host(cornell_dir, tmp_pa
     g = scene_io.compile_material_graphs([named[omm[n]].record() for n in mesh["names"]])
     assert len(progs) >= 1 and np.array_equal(progs, g["programs"]) and np.array_equal(code, g["code"])
     assert np.array_equal(spectra, g["spectra"]) and np.array_equal(vectors, g["vectors"]) and np.array_equal(scalars, g["scalars"])
+
+
+def _cpp_obj_dump(path, tmp_path):
+    import subprocess
+    cli = os.path.join(ROOT, "ray_tracer_amd", "lib", "rt_cli")
+    out = tmp_path / "obj_dump.txt"
+    p = subprocess.run([cli, "--obj", str(path), "--dump-obj", str(out)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    res = {"ok": None, "mtl": [], "v": [], "vt": [], "vn": [], "objects": []}
+    for line in out.read_text().split("\n"):
+        tok = line.split(" ")
+        if tok[0] == "ok":
+            res["ok"] = tok[1] == "1"
+        elif tok[0] == "mtl":
+            res["mtl"].append(line[5:-1])
+        elif tok[0] in ("v", "vt", "vn"):
+            res[tok[0]].append([float.fromhex(t) for t in tok[1:4]])
+        elif tok[0] == "o":
+            name, rest = line[3:].split("] [")
+            mat, s = rest.rsplit("] ", 1)
+            res["objects"].append({"name": name, "material_name": mat, "s": s == "1", "faces": []})
+        elif tok[0] == "f":
+            res["objects"][-1]["faces"].append([[None if int(i) == -1 else int(i) for i in c.split("/")] for c in tok[1:]])
+    return res
+
+
+def test_cpp_obj_parser_matches_the_python_mirror(cornell_dir, tmp_path):
+    """the C++ host's OBJ parser (a byte-level restatement of the reference's stream code, obj.cpp:6-152) against the Python mirror:
+    the reference's two Cornell files, and a file with the formats and quirks the stream code accepts"""
+    quirks = tmp_path / "quirks.obj"
+    quirks.write_text("# comment\nmtllib scene.mtl\n\no first thing\nv 1 2 3\r\nv +1.5 -.25 5.\nv 1e3 1E-3 -1.25e+2\nv 0.1234567890123456789 123456789012345678 1e-23\n"
+                      "vn 0 0 1\nvn 0.6 0.8 0 extra words\nvt 0.25 0.75\nvt 1 0 0.5\n\t \nusemtl red\ns off\nf 1//1 2//2 3//1\nf 1/1/1 2/2/2 3/1/2 4/2/1\n"
+                      "f 1//1 2//2 3//1 \nf 1 2 3\nf 1/2 2/1 3/2\no second\ns 1\nf -1//-1 2//2 3//1\t\nv 9 8 7")
+    for path in (os.path.join(cornell_dir, "cornell_box_triangulated.obj"), os.path.join(cornell_dir, "cornell_box.obj"), quirks):
+        py = scene_io.Obj()
+        assert py.Load(str(path))
+        cpp = _cpp_obj_dump(path, tmp_path)
+        assert cpp["ok"]
+        assert cpp["mtl"] == py.mtl_file
+        for k in ("v", "vt", "vn"):
+            assert cpp[k] == [list(map(float, p)) for p in getattr(py, k)], k  # bit for bit: atof on both sides
+        assert [o["name"] for o in cpp["objects"]] == py.object_names()
+        for a, b in zip(cpp["objects"], py.objects):
+            assert (a["material_name"], a["s"]) == (b["material_name"], b["s"])
+            assert a["faces"] == b["faces"]
+    assert len(cpp["objects"][0]["faces"][2]) == 4  # the trailing blank repeats the last corner (obj.cpp:105-106)
+
+
+def test_cpp_obj_parser_keeps_the_stream_quirks(tmp_path):
+    """lines the reference's stream code reads in ways of its own: a missing word leaves the previous one in place"""
+    f = tmp_path / "odd.obj"
+    f.write_text("object named\nv 1 2\nv\nvt 7\nusemtl\ns\nf \nf 1/ /2 //\n")
+    d = _cpp_obj_dump(f, tmp_path)
+    assert d["ok"] and d["objects"][0]["name"] == "named"        # any line starting with 'o' opens the first object
+    assert d["v"] == [[1.0, 2.0, 2.0], [0.0, 0.0, 0.0]]          # the missing third number repeats the second; none at all is atof("")
+    assert d["vt"] == [[7.0, 7.0, 0.0]]
+    assert d["objects"][0]["material_name"] == "usemtl" and d["objects"][0]["s"] is True
+    assert d["objects"][0]["faces"][0] == [[None, None, None]]   # "f " re-reads the word f itself: atoi("f") - 1 = -1
+    assert d["objects"][0]["faces"][1] == [[0, None, None], [None, 1, None], [None, None, None]]
+    bad = tmp_path / "bad.obj"
+    bad.write_text("o a\nv 1 2 3\ng group\n")
+    assert _cpp_obj_dump(bad, tmp_path)["ok"] is False           # an unknown first word ends the load (obj.cpp:139-142)
+    early = tmp_path / "early.obj"
+    early.write_text("v 1 2 3\no a\n")
+    assert _cpp_obj_dump(early, tmp_path)["ok"] is False         # data before the first object (obj.cpp:25-27)
+    indented = tmp_path / "indented.obj"
+    indented.write_text("o a\n  # only a '#' in the first column makes a comment\n")
+    assert _cpp_obj_dump(indented, tmp_path)["ok"] is False
