@@ -100,9 +100,16 @@ int64_t part_to_int(const char *b, const char *e)
 	while (b < e && is_space(*b)) b++;
 	bool neg = false;
 	if (b < e && (*b == '-' || *b == '+')) { neg = *b == '-'; b++; }
-	int64_t v = 0;
-	while (b < e && *b >= '0' && *b <= '9') { v = v * 10 + (*b - '0'); b++; }
-	return (int64_t)(int)(neg ? -v : v);
+	// glibc's atoi is (int)strtol: the long saturates, the conversion to int keeps the low half
+	const uint64_t limit = neg ? (uint64_t)1 << 63 : ((uint64_t)1 << 63) - 1;
+	uint64_t v = 0;
+	while (b < e && *b >= '0' && *b <= '9') {
+		const uint64_t d = (uint64_t)(*b - '0');
+		v = v > (limit - d) / 10 ? limit : v * 10 + d;
+		b++;
+	}
+	const int64_t as_long = neg ? (int64_t)(0 - v) : (int64_t)v;
+	return (int64_t)(int32_t)(uint32_t)(uint64_t)as_long;
 }
 
 std::array<int64_t, 3> corner(const Word &w)
@@ -114,7 +121,7 @@ std::array<int64_t, 3> corner(const Word &w)
 		while (q < w.e && *q != '/') q++;
 		bool blank = true;
 		for (const char *c = p; c < q; c++) blank = blank && is_space(*c);
-		if (!blank) info[k] = part_to_int(p, q) - 1;
+		if (!blank) info[k] = (int64_t)(int32_t)((uint32_t)part_to_int(p, q) - 1u); // `atoi(...) - 1` is int arithmetic in the reference
 		if (q == w.e) break; // the stream is at its end: further parts stay absent
 		p = q + 1;
 	}
