@@ -145,7 +145,7 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh);
  * 68 s per million triangles in the reference).  RT_BUILDER_HOST_SAH: binned SAH on the host threads,
  * best traversal rate.  RT_BUILDER_DEVICE_LBVH: Morton-ordered radix tree built on the GPU (870 k triangles: 15 ms against
  * 350 ms, 10 M: 0.09 s against 5 s; traversal within 1-3 % on meshes, 4.5 % on a triangle soup).  RT_BUILDER_AUTO (default):
- * the device builder above 2^17 fan triangles, else the host builder.  Hits do not depend on the choice (ties in t aside).  The
+ * the device builder above 2^15 fan triangles, else the host builder.  Hits do not depend on the choice (ties in t aside).  The
  * environment variable MI355RT_BUILDER=host|device overrides it. */
 typedef enum rt_builder { RT_BUILDER_HOST_SAH = 0, RT_BUILDER_DEVICE_LBVH = 1, RT_BUILDER_AUTO = 2 } rt_builder;
 int rt_set_builder(rt_context *ctx, int builder);

@@ -174,9 +174,10 @@ try {
 	int builder = ctx->builder;
 	if (const char *s = std::getenv("MI355RT_BUILDER")) builder = std::strcmp(s, "device") == 0 ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
 	const bool auto_chosen = builder == RT_BUILDER_AUTO;
-	// device above 2^17 fan triangles: with the cost-minimising cut its trees trace within 1-3 % of the host builder's on meshes (4.5 % on a
-	// triangle soup) and are built in 15 ms where the host takes 50-500 ms, more than a 1024-spp render of such a scene
-	if (auto_chosen) builder = nt > (1u << 17) ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
+	// device above 2^15 fan triangles (where the triangle records stop being packed): with the cost-minimising cut its trees trace within
+	// 2 % of the host builder's on meshes (35 k and 65 k triangles: +1 %, 125 k: -1.7 %, 870 k: -2 %; 4.5 % on a triangle soup) and are
+	// built in 1-10 ms where the host takes 30-500 ms, more than a 1024-spp render of such a scene loses to the slower tree
+	if (auto_chosen) builder = nt > (1u << 15) ? RT_BUILDER_DEVICE_LBVH : RT_BUILDER_HOST_SAH;
 	if (nt < 2) builder = RT_BUILDER_HOST_SAH; // the radix tree needs two leaves
 	// fp64 triangle data: v0 + face normal, v1 + v2.  The host builder writes the 128-byte leaf-ordered records of device_scene.h
 	// itself; the device builder takes the two halves in fan order and gathers the records on the GPU.

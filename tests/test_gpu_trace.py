@@ -92,7 +92,9 @@ def test_cornell_any_hit(ctx, cornell_dir):
 def test_soup_closest(ctx, n, sigma):
     mesh = synth.soup(n, sigma, seed=12345)
     sc = oracle.Scene(mesh)
+    ctx.set_builder(capi.BUILDER_HOST_SAH)  # the binary tree is kept by the host builder only
     ctx.upload_mesh(mesh)
+    ctx.set_builder(capi.BUILDER_AUTO)
     nodes, tri_index = ctx.bvh2()
     assert sorted(tri_index.tolist()) == list(range(n))
     rays = synth.incoherent_rays(100000, seed=777)
