@@ -1159,6 +1159,9 @@ __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh
 	}
 }
 
+#ifdef BDPT_COUNT
+__device__ unsigned long long g_bdpt_kind[8];
+#endif
 #include "render_bdpt.inc"
 
 // ---------------------------------------------------------------------------------------------
@@ -2136,6 +2139,13 @@ hipError_t render_set_environment(RenderState &rs, const uint8_t *texels, int wi
 
 void render_free(RenderState &rs)
 {
+#ifdef BDPT_COUNT
+	{
+		unsigned long long h[8] = {};
+		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bdpt_kind), sizeof(h));
+		std::fprintf(stderr, "[bdpt slots] t=0 %llu, t=1 %llu, pairs %llu, empty %llu\n", h[3], h[4], h[5], h[6]);
+	}
+#endif
 #ifdef SHADE_CLK
 	{
 		unsigned long long h[8] = {};
