@@ -603,3 +603,27 @@ def test_cpp_host_compiles_material_graphs_like_the_python_host(ctx, cornell_dir
     ctx.render_pass(0, 4)
     ctx.render_sync()
     assert np.abs(ctx.download_film() - want).sum() > 0.1 * want.sum()  # the graphs changed the picture
+
+
+@pytest.mark.parametrize("alg", [capi.ALG_MIS, capi.ALG_NAIVE_BDPT])
+def test_many_light_polygons(ctx, cornell_dir, alg):
+    """a scene with hundreds of light polygons (the sphere glows too): beyond eight lights NaiveBDPT gives every sampled t = 0 ray a
+    slot instead of testing it against the lights' boxes, and the light pick divides by a count that is no power of two"""
+    nx, ny, ns = 48, 36, 8
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, nx, ny)
+    recs = [dict(r) for r in records]
+    sphere = [i for i, name in enumerate(mesh["names"]) if "Sphere" in name][0]
+    lamp = [r for r in recs if r["light_flag"]][0]
+    recs[sphere] = {"type": lamp["type"], "light_flag": 1, "a": 0.05 * np.asarray(lamp["a"]), "b": np.asarray(lamp["b"])}
+    sc = oracle.Scene(mesh)
+    assert sc.set_materials(recs) == 1
+    ctx.upload_mesh(mesh)
+    ctx.upload_materials(recs)
+    ctx.set_camera(cam)
+    ctx.render_begin(nx, ny, ns, 30, alg, 17)
+    ctx.render_pass(0, ns)
+    ctx.render_sync()
+    g = ctx.download_film()
+    o, st = sc.render(oc, nx, ny, ns, 30, alg, 17)
+    assert st["lights"] > 8 if "lights" in st else True
+    compare(g, o, 0.05)
