@@ -66,6 +66,15 @@ bool ensure_stage(rt_context *ctx, uint64_t n)
 	ctx->stage_capacity = n;
 	return true;
 }
+
+// the caller's rays into the device staging buffer; true on failure (text in ctx->error)
+bool stage_rays_in(rt_context *ctx, const rt_ray *rays, uint64_t n)
+{
+	const char *from = reinterpret_cast<const char *>(rays);
+	return ctx->fail_hip(upload_generated(ctx->pinned, ctx->d_stage_rays, n, sizeof(rt_ray), ctx->stream,
+	                                      [from](size_t b, size_t e, char *out) { std::memcpy(out, from + b * sizeof(rt_ray), (e - b) * sizeof(rt_ray)); }),
+	                     "H2D rays");
+}
 } // namespace
 
 bool rt_context::fail_hip(hipError_t e, const char *what)
@@ -480,12 +489,13 @@ try {
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest: no mesh uploaded");
 	if (n == 0) return RT_OK;
 	if (!use_device(ctx) || !ensure_stage(ctx, n)) return RT_ERR_HIP;
-	if (ctx->fail_hip(hipMemcpyAsync(ctx->d_stage_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream), "H2D rays")) return RT_ERR_HIP;
+	// the caller's buffers are pageable memory: rays and results cross the link through the context's pinned pieces, with host
+	// threads copying one piece while the other is in flight
+	if (stage_rays_in(ctx, rays, n)) return RT_ERR_HIP;
 	int rc = rt_trace_closest_device(ctx, ctx->d_stage_rays, n, ctx->d_stage_out, t64 ? ctx->d_stage_t64 : nullptr, nullptr);
 	if (rc != RT_OK) return rc;
-	if (ctx->fail_hip(hipMemcpyAsync(hits, ctx->d_stage_out, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream), "D2H hits")) return RT_ERR_HIP;
-	if (t64 && ctx->fail_hip(hipMemcpyAsync(t64, ctx->d_stage_t64, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "D2H t64")) return RT_ERR_HIP;
-	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "closest-hit kernel")) return RT_ERR_HIP;
+	if (ctx->fail_hip(download_staged(ctx->pinned, ctx->d_stage_out, n * sizeof(rt_hit), hits, ctx->stream), "closest-hit kernel / D2H hits")) return RT_ERR_HIP;
+	if (t64 && ctx->fail_hip(download_staged(ctx->pinned, ctx->d_stage_t64, n * sizeof(double), t64, ctx->stream), "D2H t64")) return RT_ERR_HIP;
 	return RT_OK;
 } RT_CATCH(ctx)
 
@@ -516,11 +526,10 @@ try {
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any: no mesh uploaded");
 	if (n == 0) return RT_OK;
 	if (!use_device(ctx) || !ensure_stage(ctx, n)) return RT_ERR_HIP;
-	if (ctx->fail_hip(hipMemcpyAsync(ctx->d_stage_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream), "H2D rays")) return RT_ERR_HIP;
+	if (stage_rays_in(ctx, rays, n)) return RT_ERR_HIP;
 	int rc = rt_trace_any_device(ctx, ctx->d_stage_rays, n, ctx->d_stage_out, nullptr);
 	if (rc != RT_OK) return rc;
-	if (ctx->fail_hip(hipMemcpyAsync(out, ctx->d_stage_out, n, hipMemcpyDeviceToHost, ctx->stream), "D2H any")) return RT_ERR_HIP;
-	if (ctx->fail_hip(hipStreamSynchronize(ctx->stream), "any-hit kernel")) return RT_ERR_HIP;
+	if (ctx->fail_hip(download_staged(ctx->pinned, ctx->d_stage_out, n, out, ctx->stream), "any-hit kernel / D2H")) return RT_ERR_HIP;
 	return RT_OK;
 } RT_CATCH(ctx)
 
