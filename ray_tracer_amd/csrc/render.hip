@@ -9,7 +9,6 @@
 // being summed per path and added at the end; a NaN term is dropped on its own where the reference
 // drops the whole sample (renderer.cpp:115).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <cfloat>
 #include <chrono>
 #include <cstdio>
@@ -1825,9 +1824,7 @@ static hipError_t ensure_bdpt(Impl &im, uint64_t cap, hipStream_t stream, std::s
 	HIP_TRY(hipMalloc((void **)&im.bdpt_counts, cap * sizeof(uint32_t)));
 	HIP_TRY(hipMalloc((void **)&im.bdpt_offsets, cap * sizeof(uint32_t)));
 	HIP_TRY(hipMalloc((void **)&im.bdpt_pairs, sizeof(unsigned long long)));
-	im.bdpt_scan_bytes = 0;
-	hipcub::TransformInputIterator<uint32_t, BdptSlotCount, const uint32_t *> slot_counts(im.bdpt_counts, BdptSlotCount());
-	HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, im.bdpt_scan_bytes, slot_counts, im.bdpt_offsets, (int)cap, stream));
+	im.bdpt_scan_bytes = sizeof(uint32_t) * ((cap + kScanTile - 1) / kScanTile); // one sum per tile of the slot-count scan
 	HIP_TRY(hipMalloc(&im.bdpt_scan_tmp, std::max<size_t>(im.bdpt_scan_bytes, 1)));
 	im.bdpt_capacity = cap;
 	return hipSuccess;
@@ -1925,9 +1922,14 @@ static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &ge
 	HIP_TRY(hipMemsetAsync(im.bdpt_pairs, 0, sizeof(unsigned long long), stream));
 	hipLaunchKernelGGL(k_bdpt_pairs, dim3(std::min(blocks_n, 2048u)), dim3(kBlock), 0, stream, n, im.bdpt_counts, im.bdpt_pairs);
 	HIP_TRY(hipGetLastError());
-	size_t scan_bytes = im.bdpt_scan_bytes;
-	hipcub::TransformInputIterator<uint32_t, BdptSlotCount, const uint32_t *> slot_counts(im.bdpt_counts, BdptSlotCount());
-	HIP_TRY(hipcub::DeviceScan::ExclusiveSum(im.bdpt_scan_tmp, scan_bytes, slot_counts, im.bdpt_offsets, (int)n, stream));
+	{
+		const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
+		uint32_t *tile_sums = static_cast<uint32_t *>(im.bdpt_scan_tmp);
+		hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kBlock), 0, stream, im.bdpt_counts, n, tile_sums);
+		hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(kBlock), 0, stream, tile_sums, n_tiles);
+		hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(kBlock), 0, stream, im.bdpt_counts, n, tile_sums, im.bdpt_offsets);
+		HIP_TRY(hipGetLastError());
+	}
 	uint32_t last_off = 0, last_cnt = 0;
 	unsigned long long pairs = 0;
 	HIP_TRY(hipMemcpyAsync(&last_off, im.bdpt_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
