@@ -143,7 +143,7 @@ const char *rt_last_error(const rt_context *ctx);
 int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh);
 /* which builder the next rt_upload_mesh uses for the tree that replaces SAHBVHNode::SAHBVHNode (bvh.cpp:134-232,
  * 68 s per million triangles in the reference).  RT_BUILDER_HOST_SAH: binned SAH on one host thread.
- * RT_BUILDER_DEVICE_LBVH: Morton-ordered radix tree built on the GPU (870 k triangles: 3 ms against 350 ms, 10 M: 10 ms against
+ * RT_BUILDER_DEVICE_LBVH: Morton-ordered radix tree built on the GPU (870 k triangles: 4 ms against 350 ms, 10 M: 12 ms against
  * 5 s; traversal within 2 % of the host tree's on meshes, 4.5 % slower on a triangle soup).  RT_BUILDER_AUTO (default):
  * the device builder above 2^15 fan triangles, else the host builder.  Hits do not depend on the choice (ties in t aside).  The
  * environment variable MI355RT_BUILDER=host|device overrides it. */

@@ -6,7 +6,7 @@
 // Stages (n = fan triangles, all buffers in HBM):
 //   k_tri_boxes     fp64 vertices -> fp32 boxes rounded outward, scene bounds of the box centres (ordered-int atomics)
 //   k_morton        63-bit Morton key of each box centre (21 bits per axis)
-//   radix sort      hipcub::DeviceRadixSort (key, triangle id)
+//   radix sort      eight stable passes over eight bits of the key (k_sort_hist, k_scan_*, k_sort_scatter)
 //   k_hierarchy     binary radix tree over the sorted keys; ties between equal keys are broken by position
 //   k_fit_*         bottom up in rounds (one launch per level of readiness): boxes, subtree costs, the cut into wide nodes
 //   k_collapse      one thread per wide node and level: opens the child with the largest area until there are 8,
@@ -14,7 +14,6 @@
 //                   triangles with one atomic each, and queues the interior children for the next level
 //   k_gather        triangle records into leaf order
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <cfloat>
 #include <chrono>
 #include <cstdint>
@@ -129,6 +128,151 @@ __global__ void __launch_bounds__(kBlock) k_morton(const Box4 *__restrict__ boxe
 	}
 	keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
 	vals[i] = i;
+}
+
+// ---- radix sort of (63-bit key, triangle) pairs: eight passes over eight bits, least significant first, each pass stable.
+// Per pass: a digit histogram per tile of kSortTile keys, an exclusive prefix sum over the table in digit-major order (which is
+// the order of the output: all keys of digit 0 by tile, then digit 1, ...), and a scatter in which every key finds its rank among
+// the keys of its digit inside the tile.  32 bytes of traffic per key and pass.
+constexpr int kSortPer = 16;                      // keys per thread
+constexpr uint32_t kSortTile = kBlock * kSortPer; // keys per workgroup; wave w of the workgroup owns a contiguous quarter of them
+
+__global__ void __launch_bounds__(kBlock) k_sort_hist(const uint64_t *__restrict__ keys, uint32_t n, int shift, uint32_t *__restrict__ table, uint32_t n_tiles)
+{
+	__shared__ uint32_t hist[256];
+	hist[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t base = blockIdx.x * kSortTile;
+	for (int j = 0; j < kSortPer; j++) {
+		const uint32_t i = base + (uint32_t)j * kBlock + threadIdx.x;
+		if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 0xFFu], 1u);
+	}
+	__syncthreads();
+	table[threadIdx.x * n_tiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive prefix sum of m words in place: sums of tiles, their running sum by one workgroup, the tiles from their bases
+constexpr uint32_t kScanPer = 8, kScanTile = kBlock * kScanPer;
+
+__device__ __forceinline__ uint32_t block_inclusive_sum(uint32_t v, uint32_t *s_wave, uint32_t *total)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	uint32_t x = v;
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t t = __shfl_up(x, off);
+		if (lane >= off) x += t;
+	}
+	__syncthreads(); // s_wave may still be read from the previous call
+	if (lane == 63) s_wave[wv] = x;
+	__syncthreads();
+	uint32_t before = 0, all = 0;
+	for (int w = 0; w < kBlock / 64; w++) {
+		const uint32_t t = s_wave[w];
+		if (w < wv) before += t;
+		all += t;
+	}
+	*total = all;
+	return x + before;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_tiles(const uint32_t *__restrict__ data, uint32_t m, uint32_t *__restrict__ tile_sums)
+{
+	__shared__ uint32_t s_wave[kBlock / 64];
+	const uint32_t first = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+	uint32_t mine = 0;
+	for (uint32_t k = 0; k < kScanPer; k++)
+		if (first + k < m) mine += data[first + k];
+	uint32_t total;
+	(void)block_inclusive_sum(mine, s_wave, &total);
+	if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_spine(uint32_t *__restrict__ tile_sums, uint32_t n_tiles)
+{
+	__shared__ uint32_t s_wave[kBlock / 64];
+	uint32_t carry = 0;
+	for (uint32_t at = 0; at < n_tiles; at += kBlock) {
+		const uint32_t i = at + threadIdx.x;
+		const uint32_t v = i < n_tiles ? tile_sums[i] : 0u;
+		uint32_t total;
+		const uint32_t incl = block_inclusive_sum(v, s_wave, &total);
+		if (i < n_tiles) tile_sums[i] = carry + incl - v;
+		carry += total;
+	}
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_apply(uint32_t *__restrict__ data, uint32_t m, const uint32_t *__restrict__ tile_base)
+{
+	__shared__ uint32_t s_wave[kBlock / 64];
+	const uint32_t first = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+	uint32_t c[kScanPer], mine = 0;
+	for (uint32_t k = 0; k < kScanPer; k++) {
+		c[k] = first + k < m ? data[first + k] : 0u;
+		mine += c[k];
+	}
+	uint32_t total;
+	uint32_t run = tile_base[blockIdx.x] + block_inclusive_sum(mine, s_wave, &total) - mine;
+	for (uint32_t k = 0; k < kScanPer; k++) {
+		if (first + k < m) data[first + k] = run;
+		run += c[k];
+	}
+}
+
+// Stable scatter of one tile.  Wave w owns keys [w * 1024, (w + 1) * 1024) of the tile and goes through them 64 at a time, in
+// order: the lanes that hold the same digit find each other with eight ballots, a lane's rank among them is a population count,
+// and the number of earlier keys of that digit in the wave's part is a counter per (wave, digit) in LDS that the lowest lane of
+// each group advances.  The counters of the waves are then chained digit by digit and moved to the tile's bases in the output.
+__global__ void __launch_bounds__(kBlock) k_sort_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t n, int shift,
+                                                         const uint32_t *__restrict__ table, uint32_t n_tiles,
+                                                         uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out)
+{
+	__shared__ uint32_t count[kBlock / 64][256];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int w = 0; w < kBlock / 64; w++) count[w][threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t first = blockIdx.x * kSortTile + (uint32_t)wv * (64u * kSortPer) + (uint32_t)lane;
+	uint64_t key[kSortPer];
+	uint32_t local[kSortPer]; // digit << 16 | rank of the key among the keys of its digit in the wave's part
+	const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+	for (int j = 0; j < kSortPer; j++) {
+		const uint32_t i = first + 64u * (uint32_t)j;
+		const bool valid = i < n;
+		key[j] = valid ? keys[i] : ~0ull;
+		const uint32_t d = (uint32_t)(key[j] >> shift) & 0xFFu;
+		unsigned long long peers = __ballot(valid);
+		for (int b = 0; b < 8; b++) {
+			const bool bit = (d >> b) & 1u;
+			const unsigned long long m = __ballot(bit);
+			peers &= bit ? m : ~m;
+		}
+		const uint32_t before = count[wv][d]; // read by every lane of the group before its lowest lane adds the group's size
+		local[j] = (d << 16) | (before + (uint32_t)__popcll(peers & below));
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if (valid && (peers & below) == 0ull) count[wv][d] = before + (uint32_t)__popcll(peers);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+	__syncthreads();
+	{ // thread d: where each wave's keys of digit d start in the output
+		uint32_t run = table[threadIdx.x * n_tiles + blockIdx.x];
+		for (int w = 0; w < kBlock / 64; w++) {
+			const uint32_t c = count[w][threadIdx.x];
+			count[w][threadIdx.x] = run;
+			run += c;
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < kSortPer; j++) {
+		const uint32_t i = first + 64u * (uint32_t)j;
+		if (i < n) {
+			const uint32_t to = count[wv][local[j] >> 16] + (local[j] & 0xFFFFu);
+			keys_out[to] = key[j];
+			vals_out[to] = vals[i];
+		}
+	}
 }
 
 // Binary radix tree.  Internal node i in [0, n-1), leaf j in [0, n) = position in the sorted order.
@@ -558,11 +702,26 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	DB_TRY(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
 	hipLaunchKernelGGL(k_tri_boxes, dim3(std::min(blocks_n, kStrideBlocks)), dim3(kBlock), 0, stream, (const double2 *)d_tri_a_fan, (const double2 *)d_tri_b_fan, n, tri_boxes, bounds);
 	hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(kBlock), 0, stream, tri_boxes, n, bounds, keys, vals);
-	size_t sort_bytes = 0;
-	DB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys_sorted, vals, sorted_tri, (int)n, 0, 63, stream));
-	char *sort_tmp = nullptr;
-	DB_TRY(dalloc(sort_tmp, sort_bytes, tmp));
-	DB_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys, keys_sorted, vals, sorted_tri, (int)n, 0, 63, stream));
+	{
+		const uint32_t n_tiles = (n + kSortTile - 1) / kSortTile, m = 256u * n_tiles, scan_tiles = (m + kScanTile - 1) / kScanTile;
+		uint32_t *table = nullptr, *tile_sums = nullptr;
+		DB_TRY(dalloc(table, m, tmp));
+		DB_TRY(dalloc(tile_sums, scan_tiles, tmp));
+		uint64_t *kbuf[2] = {keys, keys_sorted};
+		uint32_t *vbuf[2] = {vals, sorted_tri};
+		for (int pass = 0; pass < 8; pass++) {
+			const int shift = 8 * pass, from = pass & 1, to = from ^ 1;
+			hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(kBlock), 0, stream, kbuf[from], n, shift, table, n_tiles);
+			hipLaunchKernelGGL(k_scan_tiles, dim3(scan_tiles), dim3(kBlock), 0, stream, table, m, tile_sums);
+			hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(kBlock), 0, stream, tile_sums, scan_tiles);
+			hipLaunchKernelGGL(k_scan_apply, dim3(scan_tiles), dim3(kBlock), 0, stream, table, m, tile_sums);
+			hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(kBlock), 0, stream, kbuf[from], vbuf[from], n, shift, table, n_tiles, kbuf[to], vbuf[to]);
+		}
+		DB_TRY(hipGetLastError());
+		// eight passes: the sorted pairs are back in the buffers the keys started in
+		std::swap(keys, keys_sorted);
+		std::swap(vals, sorted_tri);
+	}
 
 	// ---- binary tree and its boxes
 	DB_TRY(hipMemsetAsync(arrived, 0, sizeof(unsigned int) * n, stream));
