@@ -105,14 +105,14 @@ struct DeviceShade {
 	float env_brightness;
 };
 
-// 32 bytes per live path
+// 24 bytes per live path (padded to 32 it made the stores of the generate kernel and the reads of the shade kernels that much longer)
 struct PathState {
 	uint64_t rng;
 	float beta, weight;
 	uint32_t pixel;
 	uint32_t band_bounce; // band | bounce << 16
-	uint32_t pad0, pad1;
 };
+static_assert(sizeof(PathState) == 24, "PathState is stored as written");
 
 // 32 bytes per connection ray (direct-light estimate waiting for its visibility query)
 struct ConnRec {
@@ -728,7 +728,6 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevBan
 	st.weight = cam.weight_scale * c2 * c2 / (float)ns; // renderer.cpp:113-116
 	st.pixel = pixel;
 	st.band_bounce = k;
-	st.pad0 = st.pad1 = 0;
 	if (BDPT) {
 		BdptSample s{};
 		s.rng = st.rng;
