@@ -138,7 +138,7 @@ constexpr int kMaxBounces = 62; // counter slots per batch; a longer path wraps 
 #ifndef SHADE_BLOCK
 #define SHADE_BLOCK 512
 #endif
-// NaiveBDPT samples per batch, at most: 16 subpath vertices and a sample record (832 bytes), the path queues (380) and, on the
+// NaiveBDPT samples per batch, at most: 16 subpath vertices and a sample record (832 bytes), the path queues (365) and, on the
 // Cornell box, 4.6 connection slots (80 bytes each) per sample, about 1.6 KB.  Late bounces hold few walkers, and a small batch pays
 // their launches for few samples (1080p: 2^22 454 spp/s, 2^24 570, 2^25 591 with the first version of the stages; now 2^25 1061,
 // 2^26 1106, 2^27 1232): the batch is as large as fits in three quarters of the memory that is free when the first batch is set up
@@ -149,7 +149,7 @@ constexpr int kMaxBounces = 62; // counter slots per batch; a longer path wraps 
 constexpr uint64_t kBdptBytesPerSample = 1650;
 // Paths per batch of the unidirectional integrators: a batch pays the launches of its late, nearly empty bounces once, so large
 // batches are cheaper per sample (1080p NEE+MIS: 2^25 paths 3660 spp/s, 2^26 3950, 2^27 4100, 2^28 4210) and queue memory grows
-// with them (about 380 bytes per path: 51 GB at 2^27, allocated only as far as a pass needs it).  The environment variable
+// with them (about 365 bytes per path: 49 GB at 2^27, allocated only as far as a pass needs it).  The environment variable
 // MI355RT_BATCH_LOG2 (20..28), read by rt_render_begin, overrides the default.
 #ifndef PATH_BATCH_LOG2
 #define PATH_BATCH_LOG2 27
