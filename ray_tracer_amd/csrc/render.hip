@@ -114,12 +114,22 @@ struct PathState {
 };
 static_assert(sizeof(PathState) == 24, "PathState is stored as written");
 
-// 32 bytes per connection ray (direct-light estimate waiting for its visibility query)
+// 32 bytes per connection ray (direct-light estimate waiting for its visibility query); NaiveBDPT's record
 struct ConnRec {
 	float c0, c1;
 	float nx, ny, nz;
 	uint32_t sel_face, pixel, band_kind; // band | kind << 16; kind 0: MIS light sample, 1: MIS bsdf sample, 2: NEE
 };
+
+// 24 bytes: the record of the unidirectional integrators.  The connection's geometry term needs the surface normal only in its
+// product with the ray's direction, which the shade kernel has at hand: one float instead of three (the shade kernels write and
+// the connect kernel reads a quarter less per connection)
+struct alignas(8) ConnRecU {
+	float c0, c1;
+	float cos_surface; // |direction . shading normal| at the surface the ray leaves, direction normalised
+	uint32_t sel_face, pixel, band_kind;
+};
+static_assert(sizeof(ConnRecU) == 24, "ConnRecU is stored as written");
 
 // queue tails packed in one 64-bit word (low: continuation rays, high: connection rays) so that a
 // workgroup reserves its slots in both queues with a single atomic
@@ -880,7 +890,7 @@ template <int ALG, bool GRAPHS>
 __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceShade sh, const uint32_t *__restrict__ n_dev, const rt_ray *__restrict__ rays,
                                                   const PathState *__restrict__ state, const rt_hit *__restrict__ hits,
                                                   rt_ray *__restrict__ next_rays, PathState *__restrict__ next_state,
-                                                  rt_ray *__restrict__ conn_rays, ConnRec *__restrict__ conn,
+                                                  rt_ray *__restrict__ conn_rays, ConnRecU *__restrict__ conn,
                                                   Counters *__restrict__ counters, float *__restrict__ film)
 {
 	const uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
@@ -894,7 +904,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 	const bool live = idx < *n_dev;
 	bool survive = false, want_c0 = false, want_c1 = false;
 	rt_ray nr{}, cr0{}, cr1{};
-	ConnRec c0{}, c1{};
+	ConnRecU c0{}, c1{};
 	PathState st{};
 	if (live) {
 		// state, hit and ray are requested together (nearly every queued ray hits something: the ray is rarely read for nothing),
@@ -968,7 +978,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 					const float lpa = 1.0f / area / (float)sh.n_lights;
 					cr0.ox = p.x; cr0.oy = p.y; cr0.oz = p.z; cr0.tmin = tmin;
 					cr0.dx = sd.x; cr0.dy = sd.y; cr0.dz = sd.z;
-					c0.nx = nrm.x; c0.ny = nrm.y; c0.nz = nrm.z;
+					c0.cos_surface = fabsf(dot(sd, nrm));
 					c0.sel_face = lf;
 					c0.pixel = st.pixel;
 					if (ALG == RT_ALG_NEE) { // renderer.cpp:258-286
@@ -998,6 +1008,7 @@ __global__ void __launch_bounds__(kShadeBlock, SHADE_MIN_BLOCKS) k_shade(DeviceS
 							c1 = c0;
 							c1.c0 = st.beta * ratio * fabsf(gvi.z) * st.weight;
 							c1.c1 = pdfv / fabsf(gvi.z);
+							c1.cos_surface = fabsf(dot(unit(sdir), nrm));
 							c1.band_kind = band | (1u << 16);
 							// counts only if its closest hit is on the chosen light, and not at all with a zero factor
 							want_c1 = !(sh.cull_connections & 4) || (c1.c0 != 0.0f && ray_may_reach_box(sh, sel, p, sdir));
@@ -1110,7 +1121,7 @@ __device__ bool face_hit_exact(const DeviceGeom &g, const DeviceShade &sh, uint3
 // ---------------------------------------------------------------------------------------------
 template <int ALG, bool GRAPHS>
 __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh, const uint32_t *__restrict__ n_dev, const rt_ray *__restrict__ conn_rays,
-                                                    const ConnRec *__restrict__ conn, const rt_hit *__restrict__ conn_hits,
+                                                    const ConnRecU *__restrict__ conn, const rt_hit *__restrict__ conn_hits,
                                                     const uint8_t *__restrict__ conn_any, float *__restrict__ film)
 {
 	// The host only knows an upper bound of the queue length (the count of two bounces ago, or nothing better than the batch size
@@ -1118,7 +1129,7 @@ __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh
 	// there was work for, 30-60 us per kernel.  The grid is capped (stream_grid) and the queue is walked in strides.
 	const uint32_t n_items = *n_dev;
 	for (uint32_t idx = blockIdx.x * kBlock + threadIdx.x; idx < n_items; idx += gridDim.x * kBlock) {
-	const ConnRec c = conn[idx];
+	const ConnRecU c = conn[idx];
 	const DevBand bd = sh.bands[c.band_kind & 0xFFFFu];
 	const uint32_t kind = c.band_kind >> 16;
 	if (ALG == RT_ALG_NEE) {
@@ -1131,7 +1142,7 @@ __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh
 	// Both records come whole and at once (left alone the compiler reads the two words of the test below first and the rest behind
 	// it), and everything that hangs on them goes out as one batch: ray, triangle, band, emission, area.  A thread has one item in
 	// flight, so the kernel's rate is the number of resident threads over the length of this chain of dependent reads.
-	asm volatile("" : : "v"(c.c0), "v"(c.c1), "v"(c.nx), "v"(c.ny), "v"(c.nz), "v"(c.pixel), "v"(c.band_kind), "v"(h.t), "v"(h.tri), "v"(h.object));
+	asm volatile("" : : "v"(c.c0), "v"(c.c1), "v"(c.cos_surface), "v"(c.pixel), "v"(c.band_kind), "v"(h.t), "v"(h.tri), "v"(h.object));
 	if (h.prim == RT_MISS || h.prim != c.sel_face) continue; // renderer.cpp:373-376 / 419-421
 	const rt_ray r = conn_rays[idx];
 	const TriShade tri = load_tri(sh.tri_shade, h.tri);
@@ -1146,8 +1157,7 @@ __global__ void __launch_bounds__(kBlock) k_connect(DeviceGeom g, DeviceShade sh
 	// GeometryTerm(light_rec, rec), renderer.cpp:784-789
 	const f3 v = o - pl;
 	const f3 dir = unit(v);
-	const f3 nrm = F3(c.nx, c.ny, c.nz);
-	const float G = fabsf(dot(dir, ln) * dot(dir, nrm) / dot(v, v));
+	const float G = fabsf(dot(dir, ln) * c.cos_surface / dot(v, v));
 	if (programmed) light = mat_emitted<GRAPHS>(sh, lm, hit_uv(sh, h.tri, tri, pl), bd);
 	const float lpa = 1.0f / l_face_area / (float)sh.n_lights;
 	float add;
@@ -1739,10 +1749,10 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 				const dim3 grid((unsigned)((bound + kShadeBlock - 1) / kShadeBlock));
 				if (im.g_code)
 					hipLaunchKernelGGL((k_shade<ALG, true>), grid, dim3(kShadeBlock), 0, stream, sh, n_path, im.rays[cur], im.state[cur], im.hits,
-					                   im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, im.conn, &im.counters[b + 1], rs.d_film);
+					                   im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, reinterpret_cast<ConnRecU *>(im.conn), &im.counters[b + 1], rs.d_film);
 				else
 					hipLaunchKernelGGL((k_shade<ALG, false>), grid, dim3(kShadeBlock), 0, stream, sh, n_path, im.rays[cur], im.state[cur], im.hits,
-					                   im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, im.conn, &im.counters[b + 1], rs.d_film);
+					                   im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, reinterpret_cast<ConnRecU *>(im.conn), &im.counters[b + 1], rs.d_film);
 			}
 			prof.end(stream);
 			HIP_TRY(hipGetLastError());
@@ -1770,10 +1780,10 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 					prof.begin(Profiler::CONNECT, conn_bound, stream);
 					if (im.g_code)
 						hipLaunchKernelGGL((k_connect<ALG, true>), dim3(stream_grid(conn_bound, kBlock)), dim3(kBlock), 0, stream, geom, sh,
-						                   n_conn, im.conn_rays, im.conn, im.conn_hits, im.conn_any, rs.d_film);
+						                   n_conn, im.conn_rays, reinterpret_cast<const ConnRecU *>(im.conn), im.conn_hits, im.conn_any, rs.d_film);
 					else
 						hipLaunchKernelGGL((k_connect<ALG, false>), dim3(stream_grid(conn_bound, kBlock)), dim3(kBlock), 0, stream, geom, sh,
-						                   n_conn, im.conn_rays, im.conn, im.conn_hits, im.conn_any, rs.d_film);
+						                   n_conn, im.conn_rays, reinterpret_cast<const ConnRecU *>(im.conn), im.conn_hits, im.conn_any, rs.d_film);
 					prof.end(stream);
 					HIP_TRY(hipGetLastError());
 					if (rec_conn[b] >= 0) rec_conn[b] = prof.last() - 1;
