@@ -169,6 +169,27 @@ def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=
            "kernel_ms_per_launch": prof["ms"] / reps, "mrays_per_s": m * reps / (prof["ms"] * 1e-3) / 1e6,
            "hit_rate": float((d_hits[:, 1] != -1).float().mean().item()), "bvh_build_s": st["bvh_build_seconds"],
            "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"], "device_mb": st["device_bytes"] / 1e6}
+    # the library traces large unordered batches in large scenes in the order of the cells their origins lie in (64 cells; the
+    # ordering and the way back are inside the time above); the same batch without, for comparison
+    before = os.environ.get("MI355RT_RAY_BINS")
+    os.environ["MI355RT_RAY_BINS"] = "0"
+    try:
+        ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr())
+        ctx.render_sync()
+        ctx.profile_start()
+        for _ in range(reps):
+            ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr())
+        ctx.render_sync()
+        plain = ctx.profile_stop()["closest"]
+    finally:
+        if before is None:
+            del os.environ["MI355RT_RAY_BINS"]
+        else:
+            os.environ["MI355RT_RAY_BINS"] = before
+    res["unordered_kernel_ms_per_launch"] = plain["ms"] / reps
+    res["unordered_mrays_per_s"] = m * reps / (plain["ms"] * 1e-3) / 1e6
+    res["ray_ordering"] = ("library's choice: batches of at least 2^22 rays in scenes of at least 2M triangles are traced in the order of their "
+                           "origins' cells, ordering and un-ordering kernels included in kernel_ms_per_launch; unordered_* is the same batch with MI355RT_RAY_BINS=0")
     if host_buffer:
         # the host-buffer entry point (rt_trace_closest: rays and hits cross PCIe), for the record only
         t0 = time.perf_counter()

@@ -219,7 +219,11 @@ int rt_trace_closest_static(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_
 /* replaces: world->Occluded(r, t_min, t_max) (hittable.h:34-40, called at renderer.cpp:263). out[i] = 0/1 */
 int rt_trace_any(rt_context *ctx, const rt_ray *rays, uint64_t n, uint8_t *out);
 /* same, on buffers already resident in HBM, enqueued on `stream` (a hipStream_t, NULL = the
- * context's own stream); no host synchronisation. d_t64 may be NULL. */
+ * context's own stream); no host synchronisation. d_t64 may be NULL.
+ * A batch of at least 2^22 rays in a scene of at least 2M triangles is traced in the order of the cells its origins lie in (the
+ * answers come back in the caller's order and are the same ray by ray; the closest-hit call keeps 60 bytes per ray of device
+ * memory for this, grown on demand, so the first such call allocates).  MI355RT_RAY_BINS=0 in the environment switches that off,
+ * =1 on for every batch.  rt_trace_closest_static never orders. */
 int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream);
 int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_out, void *stream);
 

@@ -14,6 +14,7 @@
 #include "device_build.h"
 #include "filter.h"
 #include "parallel_for.h"
+#include "ray_bins.h"
 #include "trace.h"
 
 using namespace mi355rt;
@@ -51,6 +52,47 @@ bool dev_upload(rt_context *ctx, void *&dst, const std::vector<T> &src)
 }
 
 bool use_device(rt_context *ctx) { return !ctx->fail_hip(hipSetDevice(ctx->device), "hipSetDevice"); }
+
+void free_bins(rt_context *ctx)
+{
+	for (void **p : {&ctx->d_bin_rays, &ctx->d_bin_perm, &ctx->d_bin_hits, &ctx->d_bin_t64, &ctx->d_bin_counters}) {
+		if (*p) (void)hipFree(*p);
+		*p = nullptr;
+	}
+	ctx->bin_capacity = 0;
+}
+
+bool ensure_bins(rt_context *ctx, uint64_t n)
+{
+	if (n <= ctx->bin_capacity) return true;
+	free_bins(ctx);
+	if (ctx->fail_hip(hipMalloc(&ctx->d_bin_rays, n * sizeof(rt_ray)), "hipMalloc ordered rays") ||
+	    ctx->fail_hip(hipMalloc(&ctx->d_bin_perm, n * sizeof(uint32_t)), "hipMalloc ray permutation") ||
+	    ctx->fail_hip(hipMalloc(&ctx->d_bin_hits, n * sizeof(rt_hit)), "hipMalloc ordered hits") ||
+	    ctx->fail_hip(hipMalloc(&ctx->d_bin_t64, n * sizeof(double)), "hipMalloc ordered t64") ||
+	    ctx->fail_hip(hipMalloc(&ctx->d_bin_counters, 2 * kRayBins * sizeof(uint32_t)), "hipMalloc cell counters")) {
+		free_bins(ctx);
+		return false;
+	}
+	ctx->bin_capacity = n;
+	return true;
+}
+
+// Ordering pays where the tree and the triangle records are far larger than the caches and the batch is large enough to fill the
+// chip many times over.  Measured on 16 M unordered rays, ordering and the return of the results to the caller's order included:
+// soups of 10M / 4M / 2.5M / 1M triangles +9.5 % / +5.4 % / +3.0 % / -4.3 % (the kernel alone gains 13 % on the largest).  An
+// integrator's rays come in pixel order and go through launch_trace_closest directly.  MI355RT_RAY_BINS=0 switches the ordering
+// off, =1 on for every batch.
+constexpr uint64_t kBinMinRays = 1ull << 22, kBinMinTris = 2000000ull;
+bool bins_wanted(const rt_context *ctx, uint64_t n)
+{
+	if (n >= (1ull << 32)) return false; // the permutation holds 32-bit indices
+	if (const char *s = std::getenv("MI355RT_RAY_BINS")) {
+		if (s[0] == '0') return false;
+		if (s[0] == '1') return n > 0;
+	}
+	return n >= kBinMinRays && ctx->geom.n_tris >= kBinMinTris;
+}
 
 bool ensure_stage(rt_context *ctx, uint64_t n)
 {
@@ -139,6 +181,7 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->d_stage_rays) (void)hipFree(ctx->d_stage_rays);
 	if (ctx->d_stage_out) (void)hipFree(ctx->d_stage_out);
 	if (ctx->d_stage_t64) (void)hipFree(ctx->d_stage_t64);
+	free_bins(ctx);
 	ctx->pinned.release();
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -456,18 +499,35 @@ try {
 	return RT_OK;
 } RT_CATCH(ctx)
 
-int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream)
-try {
+// may_allocate: false for the entry point that promises to allocate nothing (it then never orders the rays)
+static int trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream, bool may_allocate)
+{
 	if (!ctx || (n && (!d_rays || !d_hits))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_device: NULL argument");
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_device: no mesh uploaded");
 	if (n >= (1ull << 32) * 256ull) return set_err(ctx, RT_ERR_INVALID, "rt_trace_closest_device: too many rays for one launch");
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+	const bool bins = may_allocate && bins_wanted(ctx, n);
+	if (bins && !ensure_bins(ctx, n)) return RT_ERR_HIP;
+	// the ordering and the way back are part of what the caller waits for: they are timed with the kernel
 	ctx->profiler.begin(Profiler::CLOSEST, n, s);
-	hipError_t e = launch_trace_closest(ctx->geom, (const rt_ray *)d_rays, n, (rt_hit *)d_hits, (double *)d_t64, s);
+	hipError_t e;
+	if (bins) {
+		e = bin_rays(ctx->geom.nodes, (const rt_ray *)d_rays, (uint32_t)n, (rt_ray *)ctx->d_bin_rays, (uint32_t *)ctx->d_bin_perm, (uint32_t *)ctx->d_bin_counters, s);
+		if (e == hipSuccess) e = launch_trace_closest(ctx->geom, (const rt_ray *)ctx->d_bin_rays, n, (rt_hit *)ctx->d_bin_hits, d_t64 ? (double *)ctx->d_bin_t64 : nullptr, s);
+		if (e == hipSuccess) e = unbin_results((const uint32_t *)ctx->d_bin_perm, (uint32_t)n, (const rt_hit *)ctx->d_bin_hits, d_t64 ? (const double *)ctx->d_bin_t64 : nullptr,
+		                                       (rt_hit *)d_hits, (double *)d_t64, s);
+	} else {
+		e = launch_trace_closest(ctx->geom, (const rt_ray *)d_rays, n, (rt_hit *)d_hits, (double *)d_t64, s);
+	}
 	ctx->profiler.end(s);
 	if (ctx->fail_hip(e, "closest-hit launch")) return RT_ERR_HIP;
 	return RT_OK;
+}
+
+int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream)
+try {
+	return trace_closest_device(ctx, d_rays, n, d_hits, d_t64, stream, true);
 } RT_CATCH(ctx)
 
 int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_out, void *stream)
@@ -512,7 +572,7 @@ try {
 	if (ctx->fail_hip(static_stage(ctx->device, st), "static staging")) return RT_ERR_HIP;
 	// nothing in the staging area has to start from zero: the kernel writes hits[i] and t64[i] for every i < n, and only those are copied back
 	if (ctx->fail_hip(hipMemcpyAsync(st.rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream), "H2D rays")) return RT_ERR_HIP;
-	int rc = rt_trace_closest_device(ctx, st.rays, n, st.hits, t64 ? st.t64 : nullptr, nullptr);
+	int rc = trace_closest_device(ctx, st.rays, n, st.hits, t64 ? st.t64 : nullptr, nullptr, false);
 	if (rc != RT_OK) return rc;
 	if (ctx->fail_hip(hipMemcpyAsync(hits, st.hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream), "D2H hits")) return RT_ERR_HIP;
 	if (t64 && ctx->fail_hip(hipMemcpyAsync(t64, st.t64, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "D2H t64")) return RT_ERR_HIP;

@@ -35,6 +35,10 @@ struct rt_context {
 	void *d_stage_rays = nullptr, *d_stage_out = nullptr, *d_stage_t64 = nullptr;
 	uint64_t stage_capacity = 0;
 	mi355rt::PinnedPieces pinned; // the scene's large tables are uploaded through these
+	// a large batch of unordered rays in a scene far larger than the caches is traced in the order of the cells its rays start in
+	// (ray_bins.h): the ordered copy, the permutation, the results in that order, the cell counters (grown on demand)
+	void *d_bin_rays = nullptr, *d_bin_perm = nullptr, *d_bin_hits = nullptr, *d_bin_t64 = nullptr, *d_bin_counters = nullptr;
+	uint64_t bin_capacity = 0;
 
 	std::vector<rt_material> materials;
 	std::vector<uint32_t> light_faces;

@@ -321,3 +321,27 @@ def test_axis_parallel_rays_are_pruned_like_any_other(ctx):
     o_poly, o_tri, o_t = sc.trace_closest(ax[:n], oracle.MODE_LIST_LOWEST)
     check_closest(hits[:n], t64[:n], o_poly, o_tri, o_t, allow_ties=False)
     assert 0.3 < (o_poly >= 0).mean()
+
+
+@pytest.mark.parametrize("builder", [capi.BUILDER_HOST_SAH, capi.BUILDER_DEVICE_LBVH])
+def test_rays_ordered_by_cell_give_the_same_answers(ctx, builder, monkeypatch):
+    """Large batches in scenes far beyond the caches are traced in the order of the cells their origins lie in and the results are
+    put back in the caller's order; MI355RT_RAY_BINS=1 asks for that on any batch.  Same ids and the same fp64 t as without, ray by
+    ray, also for origins far outside the scene, NaN origins and a batch that is not a multiple of anything."""
+    mesh = synth.soup(50000, 0.02, seed=31)
+    ctx.set_builder(builder)
+    ctx.upload_mesh(mesh)
+    ctx.set_builder(capi.BUILDER_AUTO)
+    rays = synth.incoherent_rays(100003, seed=41)
+    k = np.arange(len(rays))
+    rays[k % 50 == 0, 0:3] *= 1000.0          # far outside the root box
+    rays[k % 97 == 0, 1] = np.nan             # unsound rays: answered "miss" wherever they are filed
+    rays[k % 101 == 0, 0] = np.inf
+    monkeypatch.setenv("MI355RT_RAY_BINS", "0")
+    h0, t0 = ctx.trace_closest(rays, want_t64=True)
+    monkeypatch.setenv("MI355RT_RAY_BINS", "1")
+    h1, t1 = ctx.trace_closest(rays, want_t64=True)
+    h2 = ctx.trace_closest(rays[:777])        # a smaller batch through the same buffers, without t64
+    assert (h0["prim"] != capi.MISS).sum() > 10000
+    assert np.array_equal(h0, h1) and np.array_equal(t0, t1)
+    assert np.array_equal(h0[:777], h2)
