@@ -223,7 +223,7 @@ int rt_trace_any(rt_context *ctx, const rt_ray *rays, uint64_t n, uint8_t *out);
  * A batch of at least 2^22 rays in a scene of at least 2M triangles is traced in the order of the cells its origins lie in (the
  * answers come back in the caller's order and are the same ray by ray; the closest-hit call keeps 60 bytes per ray of device
  * memory for this, grown on demand, so the first such call allocates).  MI355RT_RAY_BINS=0 in the environment switches that off,
- * =1 on for every batch.  rt_trace_closest_static never orders. */
+ * =1 on for every batch.  rt_trace_any_device does the same; rt_trace_closest_static never orders. */
 int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream);
 int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_out, void *stream);
 

@@ -536,8 +536,17 @@ try {
 	if (!ctx->has_mesh) return set_err(ctx, RT_ERR_INVALID, "rt_trace_any_device: no mesh uploaded");
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+	const bool bins = bins_wanted(ctx, n); // as for the closest hit; the ordered answers (a byte per ray) use the buffer of the ordered hits
+	if (bins && !ensure_bins(ctx, n)) return RT_ERR_HIP;
 	ctx->profiler.begin(Profiler::ANY, n, s);
-	hipError_t e = launch_trace_any(ctx->geom, (const rt_ray *)d_rays, n, (uint8_t *)d_out, s);
+	hipError_t e;
+	if (bins) {
+		e = bin_rays(ctx->geom.nodes, (const rt_ray *)d_rays, (uint32_t)n, (rt_ray *)ctx->d_bin_rays, (uint32_t *)ctx->d_bin_perm, (uint32_t *)ctx->d_bin_counters, s);
+		if (e == hipSuccess) e = launch_trace_any(ctx->geom, (const rt_ray *)ctx->d_bin_rays, n, (uint8_t *)ctx->d_bin_hits, s);
+		if (e == hipSuccess) e = unbin_bytes((const uint32_t *)ctx->d_bin_perm, (uint32_t)n, (const uint8_t *)ctx->d_bin_hits, (uint8_t *)d_out, s);
+	} else {
+		e = launch_trace_any(ctx->geom, (const rt_ray *)d_rays, n, (uint8_t *)d_out, s);
+	}
 	ctx->profiler.end(s);
 	if (ctx->fail_hip(e, "any-hit launch")) return RT_ERR_HIP;
 	return RT_OK;

@@ -16,5 +16,7 @@ constexpr int kRayBins = 64;
 hipError_t bin_rays(const float4 *root_node, const rt_ray *rays, uint32_t n, rt_ray *sorted, uint32_t *perm, uint32_t *counters, hipStream_t stream);
 // hits[i] = sorted_hits[perm[i]] (and the same for t64 when both pointers are given)
 hipError_t unbin_results(const uint32_t *perm, uint32_t n, const rt_hit *sorted_hits, const double *sorted_t64, rt_hit *hits, double *t64, hipStream_t stream);
+// out[i] = sorted_out[perm[i]]: the any-hit answers, one byte per ray
+hipError_t unbin_bytes(const uint32_t *perm, uint32_t n, const uint8_t *sorted_out, uint8_t *out, hipStream_t stream);
 
 } // namespace mi355rt

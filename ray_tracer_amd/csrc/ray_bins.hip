@@ -118,6 +118,12 @@ __global__ void __launch_bounds__(kBinBlock) k_unbin(const uint32_t *__restrict_
 	if (t64) t64[i] = sorted_t64[p];
 }
 
+__global__ void __launch_bounds__(kBinBlock) k_unbin_bytes(const uint32_t *__restrict__ perm, uint32_t n, const uint8_t *__restrict__ sorted_out, uint8_t *__restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * kBinBlock + threadIdx.x;
+	if (i < n) out[i] = sorted_out[perm[i]];
+}
+
 } // namespace
 
 hipError_t bin_rays(const float4 *root_node, const rt_ray *rays, uint32_t n, rt_ray *sorted, uint32_t *perm, uint32_t *counters, hipStream_t stream)
@@ -140,6 +146,14 @@ hipError_t unbin_results(const uint32_t *perm, uint32_t n, const rt_hit *sorted_
 	const unsigned blocks = (unsigned)(((uint64_t)n + kBinBlock - 1) / kBinBlock);
 	hipLaunchKernelGGL(k_unbin, dim3(blocks), dim3(kBinBlock), 0, stream, perm, n, reinterpret_cast<const uint4 *>(sorted_hits), sorted_t64,
 	                   reinterpret_cast<uint4 *>(hits), t64);
+	return hipGetLastError();
+}
+
+hipError_t unbin_bytes(const uint32_t *perm, uint32_t n, const uint8_t *sorted_out, uint8_t *out, hipStream_t stream)
+{
+	if (n == 0) return hipSuccess;
+	const unsigned blocks = (unsigned)(((uint64_t)n + kBinBlock - 1) / kBinBlock);
+	hipLaunchKernelGGL(k_unbin_bytes, dim3(blocks), dim3(kBinBlock), 0, stream, perm, n, sorted_out, out);
 	return hipGetLastError();
 }
 

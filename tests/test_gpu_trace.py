@@ -345,3 +345,7 @@ def test_rays_ordered_by_cell_give_the_same_answers(ctx, builder, monkeypatch):
     assert (h0["prim"] != capi.MISS).sum() > 10000
     assert np.array_equal(h0, h1) and np.array_equal(t0, t1)
     assert np.array_equal(h0[:777], h2)
+    a1 = ctx.trace_any(rays)
+    monkeypatch.setenv("MI355RT_RAY_BINS", "0")
+    a0 = ctx.trace_any(rays)
+    assert a0.sum() > 10000 and np.array_equal(a0, a1)
