@@ -110,6 +110,9 @@ bool ensure_stage(rt_context *ctx, uint64_t n)
 }
 
 // the caller's rays into the device staging buffer; true on failure (text in ctx->error)
+// rays per part of a large host-buffer batch (rt_trace_closest): 2^22 rays are 128 MB of rays, four pinned pieces
+constexpr uint64_t kHostPart = 1ull << 22;
+
 bool stage_rays_in(rt_context *ctx, const rt_ray *rays, uint64_t n)
 {
 	const char *from = reinterpret_cast<const char *>(rays);
@@ -183,6 +186,7 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->d_stage_t64) (void)hipFree(ctx->d_stage_t64);
 	free_bins(ctx);
 	ctx->pinned.release();
+	if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -560,12 +564,48 @@ try {
 	if (!use_device(ctx) || !ensure_stage(ctx, n)) return RT_ERR_HIP;
 	// the caller's buffers are pageable memory: rays and results cross the link through the context's pinned pieces, with host
 	// threads copying one piece while the other is in flight
-	if (stage_rays_in(ctx, rays, n)) return RT_ERR_HIP;
-	int rc = rt_trace_closest_device(ctx, ctx->d_stage_rays, n, ctx->d_stage_out, t64 ? ctx->d_stage_t64 : nullptr, nullptr);
-	if (rc != RT_OK) return rc;
-	if (ctx->fail_hip(download_staged(ctx->pinned, ctx->d_stage_out, n * sizeof(rt_hit), hits, ctx->stream), "closest-hit kernel / D2H hits")) return RT_ERR_HIP;
-	if (t64 && ctx->fail_hip(download_staged(ctx->pinned, ctx->d_stage_t64, n * sizeof(double), t64, ctx->stream), "D2H t64")) return RT_ERR_HIP;
-	return RT_OK;
+	if (n <= kHostPart) { // one part: nothing to overlap
+		if (stage_rays_in(ctx, rays, n)) return RT_ERR_HIP;
+		int rc = rt_trace_closest_device(ctx, ctx->d_stage_rays, n, ctx->d_stage_out, t64 ? ctx->d_stage_t64 : nullptr, nullptr);
+		if (rc != RT_OK) return rc;
+		if (ctx->fail_hip(download_staged(ctx->pinned, ctx->d_stage_out, n * sizeof(rt_hit), hits, ctx->stream), "closest-hit kernel / D2H hits")) return RT_ERR_HIP;
+		if (t64 && ctx->fail_hip(download_staged(ctx->pinned, ctx->d_stage_t64, n * sizeof(double), t64, ctx->stream), "D2H t64")) return RT_ERR_HIP;
+		return RT_OK;
+	}
+	// A large batch goes in parts of kHostPart rays: the kernel works on part k (on the context's stream) while this thread brings
+	// the results of part k - 1 back and the rays of part k + 1 in (on a stream of their own, through the pinned pieces, one copy at
+	// a time).  The copies take twice as long as the kernel, so the kernel disappears behind them.
+	if (!ctx->copy_stream && ctx->fail_hip(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return RT_ERR_HIP;
+	hipEvent_t traced[2] = {nullptr, nullptr};
+	for (auto &ev : traced)
+		if (ctx->fail_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate")) {
+			if (traced[0]) (void)hipEventDestroy(traced[0]);
+			return RT_ERR_HIP;
+		}
+	const uint64_t n_parts = (n + kHostPart - 1) / kHostPart;
+	auto part_len = [&](uint64_t k) { return std::min<uint64_t>(kHostPart, n - k * kHostPart); };
+	auto fetch = [&](uint64_t k) -> bool { // results of part k, once its kernel is through
+		const uint64_t at = k * kHostPart, m = part_len(k);
+		if (ctx->fail_hip(hipEventSynchronize(traced[k & 1]), "closest-hit kernel")) return false;
+		if (ctx->fail_hip(download_staged(ctx->pinned, static_cast<rt_hit *>(ctx->d_stage_out) + at, m * sizeof(rt_hit), hits + at, ctx->copy_stream), "D2H hits")) return false;
+		return !(t64 && ctx->fail_hip(download_staged(ctx->pinned, static_cast<double *>(ctx->d_stage_t64) + at, m * sizeof(double), t64 + at, ctx->copy_stream), "D2H t64"));
+	};
+	int rc = RT_OK;
+	for (uint64_t k = 0; k < n_parts && rc == RT_OK; k++) {
+		const uint64_t at = k * kHostPart, m = part_len(k);
+		const char *from = reinterpret_cast<const char *>(rays + at);
+		if (ctx->fail_hip(upload_generated(ctx->pinned, static_cast<rt_ray *>(ctx->d_stage_rays) + at, m, sizeof(rt_ray), ctx->copy_stream,
+		                                   [from](size_t b, size_t e, char *out) { std::memcpy(out, from + b * sizeof(rt_ray), (e - b) * sizeof(rt_ray)); }), "H2D rays")) { rc = RT_ERR_HIP; break; }
+		rc = rt_trace_closest_device(ctx, static_cast<rt_ray *>(ctx->d_stage_rays) + at, m, static_cast<rt_hit *>(ctx->d_stage_out) + at,
+		                             t64 ? static_cast<double *>(ctx->d_stage_t64) + at : nullptr, nullptr);
+		if (rc == RT_OK && ctx->fail_hip(hipEventRecord(traced[k & 1], ctx->stream), "hipEventRecord")) rc = RT_ERR_HIP;
+		if (rc == RT_OK && k >= 1 && !fetch(k - 1)) rc = RT_ERR_HIP;
+	}
+	if (rc == RT_OK && !fetch(n_parts - 1)) rc = RT_ERR_HIP;
+	(void)hipStreamSynchronize(ctx->stream); // also after an error: nothing of this call may still run when the events go
+	(void)hipStreamSynchronize(ctx->copy_stream);
+	for (auto &ev : traced) (void)hipEventDestroy(ev);
+	return rc;
 } RT_CATCH(ctx)
 
 int rt_trace_closest_static(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64)

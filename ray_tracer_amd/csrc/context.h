@@ -14,6 +14,7 @@
 struct rt_context {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t copy_stream = nullptr; // rt_trace_closest: rays and results of one part cross the link here while the kernel works on another part (created on first use)
 	mutable std::string error;
 
 	mi355rt::HostScene host;

@@ -349,3 +349,20 @@ def test_rays_ordered_by_cell_give_the_same_answers(ctx, builder, monkeypatch):
     monkeypatch.setenv("MI355RT_RAY_BINS", "0")
     a0 = ctx.trace_any(rays)
     assert a0.sum() > 10000 and np.array_equal(a0, a1)
+
+
+def test_host_buffer_batch_in_parts(ctx):
+    """rt_trace_closest takes a batch beyond 2^22 rays in parts (copies of one part overlap the kernel of another): the same
+    answers as the same rays handed over in batches small enough to go in one part, hits and fp64 t, last short part included"""
+    mesh = synth.soup(100000, 0.01, seed=77)
+    ctx.upload_mesh(mesh)
+    n = (2 << 22) + 4099
+    rays = synth.incoherent_rays(n, seed=4242)
+    hits, t64 = ctx.trace_closest(rays, want_t64=True)
+    assert (hits["prim"] != capi.MISS).sum() > n // 4
+    step = 3000000
+    for at in range(0, n, step):
+        h, t = ctx.trace_closest(rays[at:at + step], want_t64=True)
+        assert np.array_equal(h, hits[at:at + step]) and np.array_equal(t, t64[at:at + step])
+    h2 = ctx.trace_closest(rays)  # without t64
+    assert np.array_equal(h2, hits)
