@@ -192,6 +192,7 @@ def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=
                            "origins' cells, ordering and un-ordering kernels included in kernel_ms_per_launch; unordered_* is the same batch with MI355RT_RAY_BINS=0")
     if host_buffer:
         # the host-buffer entry point (rt_trace_closest: rays and hits cross PCIe), for the record only
+        ctx.trace_closest(rays)  # the first call allocates the staging buffers, the pinned pieces and the copy streams
         t0 = time.perf_counter()
         ctx.trace_closest(rays)
         res["host_buffer_mrays_per_s"] = m / (time.perf_counter() - t0) / 1e6

@@ -1,5 +1,6 @@
 // extern "C" layer: argument checks, HIP error mapping, scene upload.  No kernels here.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -8,6 +9,7 @@
 #include <new>
 #include <algorithm>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 #include "context.h"
@@ -186,7 +188,9 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->d_stage_t64) (void)hipFree(ctx->d_stage_t64);
 	free_bins(ctx);
 	ctx->pinned.release();
+	ctx->pinned_down.release();
 	if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+	if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -572,24 +576,45 @@ try {
 		if (t64 && ctx->fail_hip(download_staged(ctx->pinned, ctx->d_stage_t64, n * sizeof(double), t64, ctx->stream), "D2H t64")) return RT_ERR_HIP;
 		return RT_OK;
 	}
-	// A large batch goes in parts of kHostPart rays: the kernel works on part k (on the context's stream) while this thread brings
-	// the results of part k - 1 back and the rays of part k + 1 in (on a stream of their own, through the pinned pieces, one copy at
-	// a time).  The copies take twice as long as the kernel, so the kernel disappears behind them.
+	// A large batch goes in parts of kHostPart rays.  This thread brings the rays of part k in (copy_stream) and launches its kernel
+	// (the context's stream); a helper thread waits for each part's kernel and brings its results back (down_stream, pinned pieces
+	// of its own).  Both directions of the link and the kernel then work at the same time, and the call takes about as long as
+	// its longest stage, the rays on their way in.
 	if (!ctx->copy_stream && ctx->fail_hip(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return RT_ERR_HIP;
-	hipEvent_t traced[2] = {nullptr, nullptr};
-	for (auto &ev : traced)
-		if (ctx->fail_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate")) {
-			if (traced[0]) (void)hipEventDestroy(traced[0]);
-			return RT_ERR_HIP;
-		}
+	if (!ctx->down_stream && ctx->fail_hip(hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking), "hipStreamCreate")) return RT_ERR_HIP;
 	const uint64_t n_parts = (n + kHostPart - 1) / kHostPart;
+	std::vector<hipEvent_t> traced(n_parts, nullptr);
+	auto drop_events = [&] { for (auto ev : traced) if (ev) (void)hipEventDestroy(ev); };
+	for (auto &ev : traced)
+		if (ctx->fail_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate")) { drop_events(); return RT_ERR_HIP; }
 	auto part_len = [&](uint64_t k) { return std::min<uint64_t>(kHostPart, n - k * kHostPart); };
-	auto fetch = [&](uint64_t k) -> bool { // results of part k, once its kernel is through
+	auto fetch = [&](uint64_t k) -> hipError_t { // results of part k, once its kernel is through
 		const uint64_t at = k * kHostPart, m = part_len(k);
-		if (ctx->fail_hip(hipEventSynchronize(traced[k & 1]), "closest-hit kernel")) return false;
-		if (ctx->fail_hip(download_staged(ctx->pinned, static_cast<rt_hit *>(ctx->d_stage_out) + at, m * sizeof(rt_hit), hits + at, ctx->copy_stream), "D2H hits")) return false;
-		return !(t64 && ctx->fail_hip(download_staged(ctx->pinned, static_cast<double *>(ctx->d_stage_t64) + at, m * sizeof(double), t64 + at, ctx->copy_stream), "D2H t64"));
+		hipError_t e = hipEventSynchronize(traced[k]);
+		if (e == hipSuccess) e = download_staged(ctx->pinned_down, static_cast<rt_hit *>(ctx->d_stage_out) + at, m * sizeof(rt_hit), hits + at, ctx->down_stream);
+		if (e == hipSuccess && t64) e = download_staged(ctx->pinned_down, static_cast<double *>(ctx->d_stage_t64) + at, m * sizeof(double), t64 + at, ctx->down_stream);
+		return e;
 	};
+	std::atomic<uint64_t> recorded{0}; // parts whose kernel has been launched and marked
+	std::atomic<bool> give_up{false};
+	hipError_t down_error = hipSuccess;
+	const int device = ctx->device;
+	auto bring_back = [&] {
+		hipError_t e = hipSetDevice(device);
+		for (uint64_t k = 0; k < n_parts && e == hipSuccess; k++) {
+			while (recorded.load(std::memory_order_acquire) <= k && !give_up.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+			if (recorded.load(std::memory_order_acquire) <= k) break; // the launching side gave up
+			e = fetch(k);
+		}
+		down_error = e;
+	};
+	std::thread helper;
+	bool threaded = true;
+	try { helper = std::thread(bring_back); } catch (const std::system_error &) { threaded = false; } // no thread to be had: this thread fetches between the parts
+	struct JoinOnExit { // an exception on this side (out of memory) must not leave the helper running with references into this frame
+		std::thread &t; std::atomic<bool> &stop;
+		~JoinOnExit() { if (t.joinable()) { stop.store(true, std::memory_order_release); t.join(); } }
+	} join_on_exit{helper, give_up};
 	int rc = RT_OK;
 	for (uint64_t k = 0; k < n_parts && rc == RT_OK; k++) {
 		const uint64_t at = k * kHostPart, m = part_len(k);
@@ -598,13 +623,22 @@ try {
 		                                   [from](size_t b, size_t e, char *out) { std::memcpy(out, from + b * sizeof(rt_ray), (e - b) * sizeof(rt_ray)); }), "H2D rays")) { rc = RT_ERR_HIP; break; }
 		rc = rt_trace_closest_device(ctx, static_cast<rt_ray *>(ctx->d_stage_rays) + at, m, static_cast<rt_hit *>(ctx->d_stage_out) + at,
 		                             t64 ? static_cast<double *>(ctx->d_stage_t64) + at : nullptr, nullptr);
-		if (rc == RT_OK && ctx->fail_hip(hipEventRecord(traced[k & 1], ctx->stream), "hipEventRecord")) rc = RT_ERR_HIP;
-		if (rc == RT_OK && k >= 1 && !fetch(k - 1)) rc = RT_ERR_HIP;
+		if (rc == RT_OK && ctx->fail_hip(hipEventRecord(traced[k], ctx->stream), "hipEventRecord")) rc = RT_ERR_HIP;
+		if (rc != RT_OK) break;
+		recorded.store(k + 1, std::memory_order_release);
+		if (!threaded && k >= 1 && ctx->fail_hip(fetch(k - 1), "closest-hit kernel / D2H")) rc = RT_ERR_HIP;
 	}
-	if (rc == RT_OK && !fetch(n_parts - 1)) rc = RT_ERR_HIP;
+	if (rc != RT_OK) give_up.store(true, std::memory_order_release);
+	if (threaded) {
+		helper.join();
+		if (rc == RT_OK && ctx->fail_hip(down_error, "closest-hit kernel / D2H")) rc = RT_ERR_HIP;
+	} else if (rc == RT_OK && ctx->fail_hip(fetch(n_parts - 1), "closest-hit kernel / D2H")) {
+		rc = RT_ERR_HIP;
+	}
 	(void)hipStreamSynchronize(ctx->stream); // also after an error: nothing of this call may still run when the events go
 	(void)hipStreamSynchronize(ctx->copy_stream);
-	for (auto &ev : traced) (void)hipEventDestroy(ev);
+	(void)hipStreamSynchronize(ctx->down_stream);
+	drop_events();
 	return rc;
 } RT_CATCH(ctx)
 

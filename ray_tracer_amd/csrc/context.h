@@ -14,7 +14,10 @@
 struct rt_context {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	hipStream_t copy_stream = nullptr; // rt_trace_closest: rays and results of one part cross the link here while the kernel works on another part (created on first use)
+	// rt_trace_closest on a large batch: the rays of one part go in on copy_stream and the results of another come back on down_stream
+	// (a helper thread, through pinned pieces of its own) while the kernel works on a third (all created on first use)
+	hipStream_t copy_stream = nullptr, down_stream = nullptr;
+	mi355rt::PinnedPieces pinned_down;
 	mutable std::string error;
 
 	mi355rt::HostScene host;
