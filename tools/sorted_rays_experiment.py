@@ -36,14 +36,30 @@ def spread(v, bits):
     return out
 
 
+def ordered(key):
+    """the rays in the order of the key; torch works on its own stream and the library on the context's, so the copy has to be complete
+    before the library is asked to trace it"""
+    r = rays[torch.argsort(key)].contiguous()
+    torch.cuda.synchronize()
+    return r
+
+
 base = timed(rays)
 print("soup %d: unordered %.3f ms, %.1f Mrays/s" % (n, base, m / base / 1e3), flush=True)
 o = rays[:, 0:3]
 lo, hi = o.min(0).values, o.max(0).values
-for bits in (2, 3, 4, 5, 7, 10):
+for bits in (2, 4):
     q = ((o - lo) / (hi - lo) * (1 << bits)).long().clamp_(0, (1 << bits) - 1)
     key = spread(q[:, 0], bits) | (spread(q[:, 1], bits) << 1) | (spread(q[:, 2], bits) << 2)
-    r = rays[torch.argsort(key)].contiguous()
-    t = timed(r)
+    t = timed(ordered(key))
     print("  %2d bits per axis (%d cells): %.3f ms, %.1f Mrays/s (%+.1f %%)" % (bits, 1 << (3 * bits), t, m / t / 1e3, (base / t - 1) * 100), flush=True)
+# the same cells, and inside a cell the octant of the direction (the kernel visits a node's children in the order the octant gives)
+d = rays[:, 4:7]
+octant = (d[:, 0] < 0).long() | ((d[:, 1] < 0).long() << 1) | ((d[:, 2] < 0).long() << 2)
+for bits in (2, 3):
+    q = ((o - lo) / (hi - lo) * (1 << bits)).long().clamp_(0, (1 << bits) - 1)
+    key = spread(q[:, 0], bits) | (spread(q[:, 1], bits) << 1) | (spread(q[:, 2], bits) << 2)
+    for name, k2 in (("cell, then octant", key * 8 + octant), ("octant, then cell", octant * (1 << (3 * bits)) + key)):
+        t = timed(ordered(k2))
+        print("  %d bits per axis, %s: %.3f ms, %.1f Mrays/s (%+.1f %%)" % (bits, name, t, m / t / 1e3, (base / t - 1) * 100), flush=True)
 ctx.close()
