@@ -297,6 +297,7 @@ def main():
     ns_total = per_rank * world
     assert parallel.sample_range(rank, world, ns_total) == (rank * per_rank, per_rank)
     film = torch.zeros(nx * ny * capi.NBINS, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # torch fills on its own stream, the library renders on the context's
     alg = {"naive": capi.ALG_NAIVE, "nee": capi.ALG_NEE, "mis": capi.ALG_MIS, "bdpt": capi.ALG_NAIVE_BDPT}[args.algorithm]
     ctx.render_begin(nx, ny, ns_total, 30, alg, 20261111, film.data_ptr())
     first = rank * per_rank

@@ -30,6 +30,7 @@ ctx = capi.Context(0)
 mesh, records, cam = scenes.cornell(nx, ny)
 ctx.upload_mesh(mesh); ctx.upload_materials(records); ctx.set_camera(cam)
 film = torch.zeros(nx * ny * capi.NBINS, dtype=torch.float32, device="cuda")
+torch.cuda.synchronize()  # torch fills on its own stream, the library renders on the context's
 ctx.render_begin(nx, ny, ns, 30, capi.ALG_MIS, seed, film.data_ptr())
 first, count = sample_range(rank, world, ns)
 # in passes of two, so that paths handed from one pass to the next take part
