@@ -138,11 +138,22 @@ def cpu_leg(args, ctx, capi, scenes, log):
                   "fp64 restatement of the reference's unpruned BVH traversal and integrator, OpenMP" % (sx, sy, sspp, st["samples"], dt),
         "msamples_per_s": st["samples"] / dt / 1e6, "rays_per_sample": st["closest_rays"] / st["samples"],
     }
+    # how the port relates to the reference itself: both timed on the same workload (Cornell 512 x 512 x 64 spp MIS) with 8 threads
+    # in the 8-vCPU build container, the reference once (1.26 Msamples/s; it cannot be built in this image), the port by
+    # tools/port_over_reference.py (committed result).  value / port_over_reference reads the figure above as the reference's.
+    try:
+        por = json.load(open(os.path.join(ROOT, "profiles", "r03_port_over_reference.json")))
+        out["cpu"]["port_over_reference"] = por["port_over_reference"]
+        out["cpu"]["reference_equivalent_value"] = out["cpu"]["value"] / por["port_over_reference"]
+        out["cpu"]["port_over_reference_source"] = ("profiles/r03_port_over_reference.json: port %.2f Msamples/s against the reference's %.2f on %d threads, %s"
+                                                    % (por["port_msamples_per_s"], por["reference_msamples_per_s"], por["threads"], por["workload"]))
+    except (OSError, KeyError, ValueError):
+        out["cpu"]["port_over_reference"] = None
     log("cpu leg: %s" % json.dumps(out))
     return out, oracle
 
 
-def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=5, host_buffer=False, builder=None):
+def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=5, host_buffer=False, builder=None, barrier=None):
     """incoherent closest hit on a random soup: Mrays/s, work units per ray, memory-side traffic from the committed PMC summary.
     builder: None leaves the library's choice (the GPU builder above 2^17 triangles); capi.BUILDER_HOST_SAH asks for the binned-SAH
     tree, which takes 50 times longer to build and traces a soup 4-5 % faster"""
@@ -159,12 +170,16 @@ def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=
     for _ in range(2):
         ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr())
     ctx.render_sync()
+    if barrier is not None:
+        barrier()
     ctx.profile_start()
+    t_wall = time.perf_counter()
     for _ in range(reps):
         ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr())
     ctx.render_sync()
+    t_wall = time.perf_counter() - t_wall
     prof = ctx.profile_stop()["closest"]
-    res = {"triangles": n, "sigma": sigma, "rays_per_launch": m, "launches": reps,
+    res = {"triangles": n, "sigma": sigma, "rays_per_launch": m, "launches": reps, "first_ray": rank * m, "wall_ms_per_launch": t_wall * 1e3 / reps,
            "builder": "library's choice (GPU: Morton radix tree, cost-minimising 8-wide cut)" if builder is None else "host binned SAH (rt_set_builder)",
            "kernel_ms_per_launch": prof["ms"] / reps, "mrays_per_s": m * reps / (prof["ms"] * 1e-3) / 1e6,
            "hit_rate": float((d_hits[:, 1] != -1).float().mean().item()), "bvh_build_s": st["bvh_build_seconds"],
@@ -207,6 +222,12 @@ def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=
         res["parity_prim_mismatch"] = int((h[:, 1] != poly).sum())
         res["parity_t_mismatch"] = int((h[:, 0].view(np.float32) != t.astype(np.float32)).sum())
         res["wide_nodes_per_ray"], res["wide_tris_per_ray"] = nv / len(sub), nt / len(sub)
+        # and by brute force over every triangle of the soup on a few rays: shares nothing with the product, not even the tree
+        nb = 256
+        bp, _, bt = sc.trace_closest(sub[:nb], oracle.MODE_LIST_LOWEST)
+        res["brute_force_rays"] = nb
+        res["brute_force_prim_mismatch"] = int((h[:nb, 1] != bp).sum())
+        res["brute_force_t_mismatch"] = int((h[:nb, 0].view(np.float32) != bt.astype(np.float32)).sum())
         res["algorithmic_bytes_per_ray"] = b_ray_wide(res["wide_nodes_per_ray"], res["wide_tris_per_ray"], 128.0)
         res["algorithmic_rate_gbs"] = res["mrays_per_s"] * 1e6 * res["algorithmic_bytes_per_ray"] / 1e9
         res["algorithmic_note"] = ("48 B + 128 B per node fetched + 128 B per triangle record tested, counted by the oracle's walk of the kernel's own tree; "
@@ -221,6 +242,30 @@ def soup_leg(n, sigma, m, tag, ctx, capi, synth, oracle, torch, rank, log, reps=
         res["line_rate_g_per_s"] = tr["read_requests_per_launch"] / (res["kernel_ms_per_launch"] * 1e-3) / 1e9
         res["frac_of_random_line_rate"] = res["line_rate_g_per_s"] / 57.0
         res["traffic_frac_hbm"] = tr["bytes_per_launch"] / (res["kernel_ms_per_launch"] * 1e-3) / HBM_PEAK
+    return res
+
+
+def over_ranks(res, world, dist, torch):
+    """adds the whole-job figures to one rank's soup result: every rank traced its own range of the ray sequence on its own replica
+    of the scene, between two barriers; the job's rate is the sum of the ranks' rays over the slowest rank's time"""
+    res["n_gpus"] = world
+    if world == 1:
+        res["mrays_per_s_total"] = res["mrays_per_s"]
+        return res
+    mine = torch.tensor([res["mrays_per_s"], res["kernel_ms_per_launch"], res["unordered_mrays_per_s"], res["hit_rate"], res["wall_ms_per_launch"]],
+                        dtype=torch.float64, device="cuda")
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    every = torch.stack(every).cpu().numpy()
+    res["per_rank_mrays_per_s"] = [float(x) for x in every[:, 0]]
+    res["mrays_per_s_min_rank"], res["mrays_per_s_max_rank"] = float(every[:, 0].min()), float(every[:, 0].max())
+    # rays of all ranks over the slowest rank's kernel time per launch (what a job that waits for every rank sees), and the plain sum
+    res["mrays_per_s_total"] = float(world * res["rays_per_launch"] / (every[:, 1].max() * 1e-3) / 1e6)
+    res["mrays_per_s_sum_of_ranks"] = float(every[:, 0].sum())
+    res["unordered_mrays_per_s_total"] = float(every[:, 2].sum())
+    res["mrays_per_s_total_wall"] = float(world * res["rays_per_launch"] / (every[:, 4].max() * 1e-3) / 1e6)
+    res["hit_rate_per_rank"] = [float(x) for x in every[:, 3]]
+    res["sharding"] = "ray ranges: rank r traces rays [r * M, (r + 1) * M) of the sequence on its own replica of the scene, no collective in the data path"
     return res
 
 
@@ -337,12 +382,17 @@ def main():
     film_mean = float(film.sum().item()) / (nx * ny) * (ns_total / (per_rank * world))
     ok = bool(torch.isfinite(film).all().item())
 
+    # the incoherent closest-hit half of the metric.  With N > 1 every rank holds a replica of the soup and traces its own range of the
+    # ray sequence, rays [rank * M, (rank + 1) * M): no exchange step, the per-rank rates are gathered afterwards and summed.
     soup = soup10 = None
-    if not args.no_soup and world == 1:  # the single-GPU half of the metric: with N > 1 every rank would build and trace the same soups
-        soup = soup_leg(args.soup_tris, args.soup_sigma, args.soup_rays, "soup1m", ctx, capi, synth, oracle, torch, rank, log, host_buffer=True,
-                        builder=capi.BUILDER_HOST_SAH)
+    barrier = dist.barrier if world > 1 else None
+    if not args.no_soup:
+        soup = soup_leg(args.soup_tris, args.soup_sigma, args.soup_rays, "soup1m", ctx, capi, synth, oracle, torch, rank, log, host_buffer=(world == 1),
+                        builder=capi.BUILDER_HOST_SAH, barrier=barrier)
+        soup = over_ranks(soup, world, dist, torch)
         if not args.no_soup10m:
-            soup10 = soup_leg(10_000_000, 0.002, args.soup_rays, "soup10m", ctx, capi, synth, oracle, torch, rank, log, reps=3)
+            soup10 = soup_leg(10_000_000, 0.002, args.soup_rays, "soup10m", ctx, capi, synth, oracle, torch, rank, log, reps=3, barrier=barrier)
+            soup10 = over_ranks(soup10, world, dist, torch)
 
     if rank == 0:
         k = prof["closest"]

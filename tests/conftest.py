@@ -20,3 +20,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def cornell_dir():
     return os.path.join(ROOT, "tests", "golden", "cornell")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")

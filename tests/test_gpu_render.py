@@ -63,6 +63,46 @@ def test_cornell_film_matches_oracle(ctx, cornell_dir, alg, rmse_bound):
     assert gs["camera_samples"] == st["samples"] == 64 * 48 * 8
 
 
+@pytest.mark.parametrize("ns", [1024, 4096])
+def test_film_accumulation_depth(ctx, cornell_dir, ns):
+    """the film at the benchmark configurations' sample counts: the product accumulates rad / ns into an fp32 film with atomics, in
+    passes, where the reference adds doubles (Spectrum::add, spectrum.cpp:148-155, called at renderer.cpp:116).  32 x 32 pixels, MIS,
+    30 bands, against the oracle's fp64 film of the same samples, same tolerances as at 8 spp"""
+    nx = ny = 32
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, nx, ny)
+    sc = oracle.Scene(mesh)
+    assert sc.set_materials(records) == 1
+    ctx.upload_mesh(mesh)
+    ctx.upload_materials(records)
+    ctx.set_camera(cam)
+    ctx.render_begin(nx, ny, ns, 30, capi.ALG_MIS, 42)
+    for s in range(0, ns, 640):  # passes that do not divide the sample count
+        ctx.render_pass(s, min(640, ns - s))
+    ctx.render_sync()
+    g = ctx.download_film()
+    o, st = sc.render(oc, nx, ny, ns, 30, capi.ALG_MIS, 42)
+    frac, rmse = compare(g, o, 0.05)
+    # per bin, the largest deviation relative to the pixel's brightest bin: what fp32 accumulation over ns terms may cost
+    worst = float((np.abs(g - o).max(1) / np.maximum(o.max(1), 1e-12)).max())
+    print("ns", ns, "pixels within 1e-3:", frac, "relative rmse:", rmse, "worst bin deviation relative to its pixel's maximum:", worst)
+    assert ctx.stats()["camera_samples"] == st["samples"] == nx * ny * ns
+
+
+@pytest.mark.parametrize("name,alg", [("mis", capi.ALG_MIS), ("nee", capi.ALG_NEE)])
+def test_cornell_film_matches_committed_oracle_film(ctx, cornell_dir, golden_dir, name, alg):
+    """against the oracle films committed under tests/golden/ (64 x 48 x 8, seed 42; tests/golden/make_golden_films.py): an edit
+    that moved the oracle and the kernels together would pass the live comparison above and fail here"""
+    want = np.load(os.path.join(golden_dir, "oracle_films.npz"))[name]
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 64, 48)
+    ctx.upload_mesh(mesh)
+    ctx.upload_materials(records)
+    ctx.set_camera(cam)
+    ctx.render_begin(64, 48, 8, 30, alg, 42)
+    ctx.render_pass(0, 8)
+    ctx.render_sync()
+    compare(ctx.download_film(), want.astype(np.float64), 0.05)
+
+
 def test_spectral_sample_counts(ctx, cornell_dir):
     # bands wider than a bin (10 bands of 30 nm), and bands that straddle bins (7 bands)
     for S in (10, 7, 1):

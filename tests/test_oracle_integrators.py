@@ -141,3 +141,17 @@ def test_naive_bdpt_aggregates(cornell_dir):
     assert 1.4 < film.sum() / mis.sum() < 2.0
     black, _ = sc.render(oc, 16, 16, 2, 30, oracle.ALG_MIS_BDPT, seed=1)
     assert not black.any()
+
+
+def test_oracle_reproduces_its_committed_films(cornell_dir, golden_dir):
+    """the oracle against its own films committed under tests/golden/ (make_golden_films.py): an edit to the oracle that changes
+    what it renders is noticed here, and the GPU tests compare the kernels with the same files"""
+    import os
+    want = np.load(os.path.join(golden_dir, "oracle_films.npz"))
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 64, 48)
+    sc = oracle.Scene(mesh)
+    assert sc.set_materials(records) == 1
+    for name, alg in (("mis", oracle.ALG_MIS), ("nee", oracle.ALG_NEE)):
+        film, st = sc.render(oc, 64, 48, 8, 30, alg, 42)
+        # fp64 on another host may contract or order libm calls differently in the last place: equal up to 1e-9 of each pixel
+        assert np.allclose(film, want[name], rtol=1e-9, atol=1e-15), name
