@@ -209,8 +209,11 @@ int rt_clear(rt_context *ctx);
  * Host buffers; t64 (optional, may be NULL) receives rec.t in double, +inf on a miss.
  * Ties in t between different polygons resolve to the lowest fan-triangle index. */
 int rt_trace_closest(rt_context *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64);
-/* rt_trace_closest for callers that may not allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc).  No counterpart in the reference.  Same arguments and results as rt_trace_closest, but the device-side staging of
+/* rt_trace_closest for callers that may not allocate (tight serving loops, harnesses that forbid hipMalloc / hipFree while
+ * they run).  No counterpart in the reference.  Synchronous like rt_trace_closest: it copies from and to the caller's host
+ * buffers on the context's own stream and waits for it, so it is not something to call while a stream is being captured into a
+ * HIP graph (such a caller wants rt_trace_closest_device on resident buffers, which enqueues only and, below the sizes at which
+ * batches are ordered, allocates nothing either).  Same arguments and results as rt_trace_closest, but the device-side staging of
  * rays, hits and t64 lives in a file-scope device array of the library (56 MiB per GPU, held from library load to process end)
  * instead of buffers grown with hipMalloc: the call allocates and frees nothing.  n > RT_STATIC_MAX_RAYS is refused with
  * RT_ERR_INVALID.  All contexts of one GPU share that GPU's array: calls that overlap on one GPU race (serialise them). */
@@ -223,7 +226,10 @@ int rt_trace_any(rt_context *ctx, const rt_ray *rays, uint64_t n, uint8_t *out);
  * A batch of at least 2^22 rays in a scene of at least 2M triangles is traced in the order of the cells its origins lie in (the
  * answers come back in the caller's order and are the same ray by ray; the closest-hit call keeps 60 bytes per ray of device
  * memory for this, grown on demand, so the first such call allocates).  MI355RT_RAY_BINS=0 in the environment switches that off,
- * =1 on for every batch.  rt_trace_any_device does the same; rt_trace_closest_static never orders. */
+ * =1 on for every batch.  rt_trace_any_device does the same; rt_trace_closest_static never orders.
+ * Those buffers belong to the context, not to the batch: ordered batches of one context run one after the other even when they
+ * are enqueued on different streams (the later stream waits on the device for the earlier batch's results to be out; the host
+ * never waits).  Batches that are not ordered keep no state and overlap freely.  One context serves one host thread at a time. */
 int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream);
 int rt_trace_any_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_out, void *stream);
 

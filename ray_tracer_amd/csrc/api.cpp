@@ -64,6 +64,20 @@ void free_bins(rt_context *ctx)
 	ctx->bin_capacity = 0;
 }
 
+// Enqueue-only ordering of the shared bin buffers between batches on different streams: bins_acquire makes `s` wait for the batch
+// that used them last, bins_release marks the end of this batch's use.
+bool bins_acquire(rt_context *ctx, hipStream_t s)
+{
+	if (!ctx->bin_done && ctx->fail_hip(hipEventCreateWithFlags(&ctx->bin_done, hipEventDisableTiming), "hipEventCreate (ray ordering)")) return false;
+	if (ctx->bin_in_use && ctx->fail_hip(hipStreamWaitEvent(s, ctx->bin_done, 0), "hipStreamWaitEvent (ray ordering)")) return false;
+	return true;
+}
+void bins_release(rt_context *ctx, hipStream_t s)
+{
+	if (hipEventRecord(ctx->bin_done, s) == hipSuccess) ctx->bin_in_use = true;
+	else (void)hipStreamSynchronize(s); // cannot mark the end of this batch: let it finish before anyone else may touch the buffers
+}
+
 bool ensure_bins(rt_context *ctx, uint64_t n)
 {
 	if (n <= ctx->bin_capacity) return true;
@@ -187,6 +201,7 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->d_stage_out) (void)hipFree(ctx->d_stage_out);
 	if (ctx->d_stage_t64) (void)hipFree(ctx->d_stage_t64);
 	free_bins(ctx);
+	if (ctx->bin_done) (void)hipEventDestroy(ctx->bin_done);
 	ctx->pinned.release();
 	ctx->pinned_down.release();
 	if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -516,7 +531,7 @@ static int trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n,
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
 	const bool bins = may_allocate && bins_wanted(ctx, n);
-	if (bins && !ensure_bins(ctx, n)) return RT_ERR_HIP;
+	if (bins && (!ensure_bins(ctx, n) || !bins_acquire(ctx, s))) return RT_ERR_HIP;
 	// the ordering and the way back are part of what the caller waits for: they are timed with the kernel
 	ctx->profiler.begin(Profiler::CLOSEST, n, s);
 	hipError_t e;
@@ -525,6 +540,7 @@ static int trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n,
 		if (e == hipSuccess) e = launch_trace_closest(ctx->geom, (const rt_ray *)ctx->d_bin_rays, n, (rt_hit *)ctx->d_bin_hits, d_t64 ? (double *)ctx->d_bin_t64 : nullptr, s);
 		if (e == hipSuccess) e = unbin_results((const uint32_t *)ctx->d_bin_perm, (uint32_t)n, (const rt_hit *)ctx->d_bin_hits, d_t64 ? (const double *)ctx->d_bin_t64 : nullptr,
 		                                       (rt_hit *)d_hits, (double *)d_t64, s);
+		bins_release(ctx, s);
 	} else {
 		e = launch_trace_closest(ctx->geom, (const rt_ray *)d_rays, n, (rt_hit *)d_hits, (double *)d_t64, s);
 	}
@@ -545,13 +561,14 @@ try {
 	if (!use_device(ctx)) return RT_ERR_HIP;
 	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
 	const bool bins = bins_wanted(ctx, n); // as for the closest hit; the ordered answers (a byte per ray) use the buffer of the ordered hits
-	if (bins && !ensure_bins(ctx, n)) return RT_ERR_HIP;
+	if (bins && (!ensure_bins(ctx, n) || !bins_acquire(ctx, s))) return RT_ERR_HIP;
 	ctx->profiler.begin(Profiler::ANY, n, s);
 	hipError_t e;
 	if (bins) {
 		e = bin_rays(ctx->geom.nodes, (const rt_ray *)d_rays, (uint32_t)n, (rt_ray *)ctx->d_bin_rays, (uint32_t *)ctx->d_bin_perm, (uint32_t *)ctx->d_bin_counters, s);
 		if (e == hipSuccess) e = launch_trace_any(ctx->geom, (const rt_ray *)ctx->d_bin_rays, n, (uint8_t *)ctx->d_bin_hits, s);
 		if (e == hipSuccess) e = unbin_bytes((const uint32_t *)ctx->d_bin_perm, (uint32_t)n, (const uint8_t *)ctx->d_bin_hits, (uint8_t *)d_out, s);
+		bins_release(ctx, s);
 	} else {
 		e = launch_trace_any(ctx->geom, (const rt_ray *)d_rays, n, (uint8_t *)d_out, s);
 	}
@@ -854,9 +871,17 @@ int for_each_member(rt_group *g, F f)
 	std::vector<int> rc(n, RT_OK);
 	if (n == 1) rc[0] = f(0);
 	else {
+		// one host thread per member; members whose thread cannot be started are served by the calling thread, after the others
+		// have been joined (a vector of joinable threads must never be destroyed: that ends the process)
 		std::vector<std::thread> th;
-		for (size_t i = 0; i < n; i++) th.emplace_back([&, i] { rc[i] = f(i); });
+		th.reserve(n);
+		size_t started = 0;
+		try {
+			for (; started < n; started++) th.emplace_back([&rc, &f, i = started] { rc[i] = f(i); });
+		} catch (const std::system_error &) {
+		}
 		for (auto &t : th) t.join();
+		for (size_t i = started; i < n; i++) rc[i] = f(i);
 	}
 	for (size_t i = 0; i < n; i++)
 		if (rc[i] != RT_OK) {

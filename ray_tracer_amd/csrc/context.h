@@ -43,6 +43,11 @@ struct rt_context {
 	// (ray_bins.h): the ordered copy, the permutation, the results in that order, the cell counters (grown on demand)
 	void *d_bin_rays = nullptr, *d_bin_perm = nullptr, *d_bin_hits = nullptr, *d_bin_t64 = nullptr, *d_bin_counters = nullptr;
 	uint64_t bin_capacity = 0;
+	// the buffers above are shared by every batch of the context: a batch enqueued on one stream must not reorder its rays into
+	// them while an earlier batch on another stream still reads its results out of them.  Recorded behind the last kernel that
+	// reads them; the next batch's stream waits for it (no host synchronisation: a wait on an event of the same stream is free).
+	hipEvent_t bin_done = nullptr;
+	bool bin_in_use = false;
 
 	std::vector<rt_material> materials;
 	std::vector<uint32_t> light_faces;

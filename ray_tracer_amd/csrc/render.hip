@@ -2075,10 +2075,21 @@ static hipError_t download_widened(Impl &im, const float *src, size_t n, double 
 	// to the caller's doubles while the next one arrives.  (Widened on the device and copied as doubles into pageable memory, 1080p
 	// took 58 ms and 4K 300 ms: twice the bytes at a fifth of the link's rate.)
 	constexpr size_t kPiece = 8u << 20; // floats
-	if (!im.stage[0]) {
-		for (int k = 0; k < 2; k++) {
-			HIP_TRY(hipHostMalloc((void **)&im.stage[k], kPiece * sizeof(float), hipHostMallocDefault));
-			HIP_TRY(hipEventCreateWithFlags(&im.stage_ev[k], hipEventDisableTiming));
+	if (!im.stage[0] || !im.stage[1] || !im.stage_ev[0] || !im.stage_ev[1]) { // all four or none: a partial set is given back
+		hipError_t e = hipSuccess;
+		for (int k = 0; k < 2 && e == hipSuccess; k++) {
+			if (!im.stage[k]) e = hipHostMalloc((void **)&im.stage[k], kPiece * sizeof(float), hipHostMallocDefault);
+			if (e == hipSuccess && !im.stage_ev[k]) e = hipEventCreateWithFlags(&im.stage_ev[k], hipEventDisableTiming);
+		}
+		if (e != hipSuccess) {
+			for (int k = 0; k < 2; k++) {
+				if (im.stage[k]) (void)hipHostFree(im.stage[k]);
+				if (im.stage_ev[k]) (void)hipEventDestroy(im.stage_ev[k]);
+				im.stage[k] = nullptr;
+				im.stage_ev[k] = nullptr;
+			}
+			err = std::string("pinned pieces of the film download: ") + hipGetErrorString(e);
+			return e;
 		}
 	}
 	const size_t n_pieces = (n + kPiece - 1) / kPiece;
@@ -2096,11 +2107,8 @@ static hipError_t download_widened(Impl &im, const float *src, size_t n, double 
 		const size_t at = c * kPiece, m = std::min(kPiece, n - at);
 		const float *from = im.stage[c & 1];
 		double *to = out + at;
-		auto widen = [from, to](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) to[i] = (double)from[i]; };
-		std::vector<std::thread> workers;
-		for (int t = 1; t < n_threads; t++) workers.emplace_back(widen, m * t / n_threads, m * (t + 1) / n_threads);
-		widen(0, m / n_threads);
-		for (auto &w : workers) w.join();
+		// host threads share the widening; a thread that cannot be started leaves its part to the calling thread (parallel_for)
+		parallel_for(m, std::max<uint64_t>(1, m / (uint64_t)n_threads), [from, to](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) to[i] = (double)from[i]; });
 	}
 	if (e != hipSuccess) (void)hipStreamSynchronize(stream); // nothing may still be writing the pinned pieces when they are reused
 	return e;

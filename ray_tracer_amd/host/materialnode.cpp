@@ -1,4 +1,5 @@
 #include "materialnode.h"
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -439,6 +440,12 @@ rt_material NodeMaterial::Record() const
 		a = own_array(nodes[b], "n");
 		bb = own_array(nodes[b], "k");
 		r.roughness = nodes[b].contains("roughness") ? nodes[b].at("roughness").number(0.5) : 0.5;
+		static bool warned = false; // once per process: such a scene renders the defined variant, not numbers of the reference
+		if (!warned) {
+			warned = true;
+			std::fprintf(stderr, "mi355rt: material %s uses GGXReflection, which is undefined in the reference (uninitialised alpha, BSDF()/PDF() return nothing); "
+			                     "rendering the backend's defined variant RT_MAT_GGX with alpha from the node's \"roughness\" key (0.5 without one)\n", name.c_str());
+		}
 	}
 	else throw UnsupportedMaterialGraph("node type " + t + " wired to the BSDF output of " + name);
 	for (int i = 0; i < N; i++) { r.a[i] = a[i]; r.b[i] = bb[i]; }

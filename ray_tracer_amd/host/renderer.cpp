@@ -129,8 +129,13 @@ void Renderer::RenderImage(int nx, int ny, int ns, int spectral_samples, bool, b
 	int s = 0;
 	while (s < ns) {
 		if (stop_rendering) break; // once per pass, renderer.cpp:70
+		// samples_per_pass = 0: the library's choice.  Unwatched, a pass is one full device batch (2^27 paths: tens of milliseconds,
+		// so stop_rendering is still looked at many times a second).  With a preview or progress output wanted the reference serves
+		// them once per sample (renderer.cpp:69-151); here a watched render reports at least a hundred times.
 		const long long fill = std::max(1LL, (1LL << 27) / std::max(1LL, (long long)nx * ny));
-		int b = (int)std::min<long long>(samples_per_pass > 0 ? samples_per_pass : fill, ns - s);
+		const long long want = samples_per_pass > 0 ? samples_per_pass
+		                       : (preview_img_flag || print_progress) ? std::max(1LL, std::min<long long>(fill, ns / 100)) : fill;
+		int b = (int)std::min<long long>(want, ns - s);
 		if (rt_group_render_pass(gpu, s, b) != RT_OK) { // no sync here: the pass's last paths ride along with the next pass; the downloads finish them
 			last_error = rt_group_last_error(gpu);
 			std::fprintf(stderr, "%s\n", last_error.c_str());

@@ -91,8 +91,17 @@ class Renderer:
         while s < ns:
             if self.stop_rendering:  # checked once per pass, renderer.cpp:70
                 break
+            # samples_per_pass = 0: the library's choice.  Unwatched, a pass is one full device batch (2^27 paths: tens of
+            # milliseconds, so stop_rendering is still looked at many times a second).  With a preview or progress output wanted the
+            # reference serves them once per sample (renderer.cpp:69-151); here a watched render reports at least a hundred times.
             fill = max(1, (1 << 27) // max(1, nx * ny))
-            b = min(self.samples_per_pass if self.samples_per_pass > 0 else fill, ns - s)
+            if self.samples_per_pass > 0:
+                want = self.samples_per_pass
+            elif self.preview_img_flag or print_progress:
+                want = max(1, min(fill, ns // 100))
+            else:
+                want = fill
+            b = min(want, ns - s)
             self.ctx.render_pass(s, b)  # no sync: the pass's last paths ride along with the next pass; the downloads finish them
             s += b
             if self.preview_img_flag or s == ns:

@@ -458,6 +458,20 @@ def write_ply(path, vertices, faces, normals=None, binary=False):
 # ----------------------------------------------------------------------------------------------
 # material node graphs (materialnode.cpp)
 # ----------------------------------------------------------------------------------------------
+_ggx_warned = False
+
+
+def _warn_ggx_once(name):
+    """a scene that wires GGXReflection renders the backend's defined variant, not numbers of the reference (which has none for it:
+    its node is undefined behaviour): say so once per process instead of silently"""
+    global _ggx_warned
+    if not _ggx_warned:
+        _ggx_warned = True
+        import sys
+        print("mi355rt: material %s uses GGXReflection, which is undefined in the reference (uninitialised alpha, BSDF()/PDF() return nothing); "
+              "rendering the backend's defined variant RT_MAT_GGX with alpha from the node's \"roughness\" key (0.5 without one)" % name, file=sys.stderr)
+
+
 class UnsupportedMaterialGraph(ValueError):
     """The graph cannot be turned into a material record: a node the reference leaves undefined (GGX), a cycle, a texture
     file in a format that is not decoded here."""
@@ -751,6 +765,7 @@ class NodeMaterial:
             # the reference reads an uninitialised alpha and returns no value from BSDF()/PDF() (materialnode.cpp:647-695): the
             # backend runs a well-defined variant (RT_MAT_GGX) with alpha from the node's "roughness" key, 0.5 without one
             rec.update(type=capi.MAT_GGX, a=own("n"), b=own("k"), roughness=float(node.get("roughness", 0.5)))
+            _warn_ggx_once(self.name)
         else:
             raise UnsupportedMaterialGraph("node type %s wired to the BSDF output of %s" % (t, self.name))
         return rec

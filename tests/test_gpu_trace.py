@@ -351,6 +351,40 @@ def test_rays_ordered_by_cell_give_the_same_answers(ctx, builder, monkeypatch):
     assert a0.sum() > 10000 and np.array_equal(a0, a1)
 
 
+def test_ordered_batches_on_two_streams_do_not_share_buffers_at_once(ctx, monkeypatch):
+    """Two ordered batches of one context enqueued back to back on two different streams, without a host wait between them: the
+    ordering goes through buffers that belong to the context, so the second batch must wait (on the device) until the first one's
+    results are out.  Both must equal the unordered answers."""
+    import torch
+    mesh = synth.soup(200000, 0.01, seed=5)
+    ctx.upload_mesh(mesh)
+    n = 1 << 21
+    ra, rb = synth.incoherent_rays(n, seed=91), synth.incoherent_rays(n, seed=92)
+    da, db = torch.from_numpy(ra).cuda(), torch.from_numpy(rb).cuda()
+    want = []
+    monkeypatch.setenv("MI355RT_RAY_BINS", "0")
+    for d in (da, db):
+        h = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+        t = torch.empty(n, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.trace_closest_device(d.data_ptr(), n, h.data_ptr(), t.data_ptr())
+        ctx.render_sync()
+        want.append((h.cpu().numpy(), t.cpu().numpy()))
+    assert not np.array_equal(want[0][0], want[1][0])
+    monkeypatch.setenv("MI355RT_RAY_BINS", "1")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(3):
+        ha, hb = torch.zeros((n, 4), dtype=torch.int32, device="cuda"), torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+        ta, tb = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.trace_closest_device(da.data_ptr(), n, ha.data_ptr(), ta.data_ptr(), stream=s1.cuda_stream)
+        ctx.trace_closest_device(db.data_ptr(), n, hb.data_ptr(), tb.data_ptr(), stream=s2.cuda_stream)
+        ctx.trace_closest_device(da.data_ptr(), n, ha.data_ptr(), ta.data_ptr(), stream=s1.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(ha.cpu().numpy(), want[0][0]) and np.array_equal(ta.cpu().numpy(), want[0][1])
+        assert np.array_equal(hb.cpu().numpy(), want[1][0]) and np.array_equal(tb.cpu().numpy(), want[1][1])
+
+
 def test_host_buffer_batch_in_parts(ctx):
     """rt_trace_closest takes a batch beyond 2^22 rays in parts (copies of one part overlap the kernel of another): the same
     answers as the same rays handed over in batches small enough to go in one part, hits and fp64 t, last short part included"""
