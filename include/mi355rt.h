@@ -329,6 +329,12 @@ typedef struct rt_wide_node {
 /* copies the wide tree (n_nodes records, node 0 = root) and its leaf order (leaf position -> fan triangle), whichever builder made
  * it.  Pass NULL pointers to query the counts only.  For work counting and tests. */
 int rt_get_wide_bvh(rt_context *ctx, rt_wide_node *nodes, uint64_t *n_nodes, uint32_t *tri_index, uint64_t *n_tris);
+/* The box that the tree builders give fan triangle (a, b, c) of a polygon with unit face normal nf (host arithmetic, no device
+ * needed; for tests).  No counterpart in the reference, which tests every fan triangle on the plane of the polygon's first three
+ * vertices (object.cpp:244) and therefore, for a polygon that is not planar, accepts hit points outside the triangle and outside
+ * its vertices' box: this box holds every point that test can accept, so that the closest hit found through the tree is the one
+ * a loop over all polygons (HittableList::Hit, hittablelist.cpp:3-17) finds. */
+void rt_accept_region_box(const double a[3], const double b[3], const double c[3], const double nf[3], double lo[3], double hi[3]);
 /* replaces: BiliteralFilter::FilterImage (filter.cpp:13-51; window / sigma_d / sigma_r are the public fields of filter.h:17-27).
  * rgba, out: width * height * 4 doubles, row major, as Filter::orig_img / Filter::result.  Host buffers. */
 int rt_filter_bilateral(rt_context *ctx, const double *rgba, int width, int height, int window, double sigma_d, double sigma_r, double *out);

@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_group_create", "rt_group_destroy", "rt_group_last_error", "rt_group_size", "rt_group_context", "rt_group_upload_mesh",
     "rt_group_upload_materials", "rt_group_upload_material_graphs", "rt_group_set_environment", "rt_group_set_camera", "rt_group_clear",
     "rt_group_render_begin", "rt_group_render_pass", "rt_group_render_sync", "rt_group_download_film", "rt_group_download_preview",
-    "rt_get_stats", "rt_get_bvh2", "rt_get_wide_bvh", "rt_filter_bilateral", "rt_filter_bilateral_device", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays",
+    "rt_get_stats", "rt_get_bvh2", "rt_get_wide_bvh", "rt_filter_bilateral", "rt_filter_bilateral_device", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays", "rt_accept_region_box",
 ]
 
 RAY_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("oz", "f4"), ("tmin", "f4"),
@@ -131,6 +131,8 @@ def load():
     lib.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.rt_get_bvh2.argtypes = [vp, vp, C.POINTER(u64), vp, C.POINTER(u64)]
     lib.rt_get_wide_bvh.argtypes = [vp, vp, C.POINTER(u64), vp, C.POINTER(u64)]
+    lib.rt_accept_region_box.argtypes = [vp] * 6
+    lib.rt_accept_region_box.restype = None
     lib.rt_stream.argtypes = [vp]
     lib.rt_stream.restype = vp
     lib.rt_profile_start.argtypes = [vp]

@@ -15,6 +15,7 @@
 #include "context.h"
 #include "device_build.h"
 #include "filter.h"
+#include "accept_region.h"
 #include "parallel_for.h"
 #include "ray_bins.h"
 #include "trace.h"
@@ -547,6 +548,11 @@ static int trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n,
 	ctx->profiler.end(s);
 	if (ctx->fail_hip(e, "closest-hit launch")) return RT_ERR_HIP;
 	return RT_OK;
+}
+
+void rt_accept_region_box(const double a[3], const double b[3], const double c[3], const double nf[3], double lo[3], double hi[3])
+{
+	accept_region_box(a, b, c, nf, lo, hi);
 }
 
 int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream)

@@ -1,4 +1,5 @@
 #include "bvh_builder.h"
+#include "accept_region.h"
 
 #include <algorithm>
 #include <atomic>
@@ -425,10 +426,14 @@ void build_bvh(const HostScene &scene, const BvhBuildOptions &opt_in, Bvh2 &out,
 		const double *v0, *v1, *v2;
 		scene.tri_vertices(t, v0, v1, v2);
 		Box bx;
+		// the box of everything the reference's test of this fan triangle can accept: the vertices' box for a planar polygon,
+		// more for a polygon that is not (accept_region.h)
+		double rlo[3], rhi[3];
+		accept_region_box(v0, v1, v2, &scene.face_normal[3 * (size_t)scene.tri_face[t]], rlo, rhi);
 		for (int a = 0; a < 3; a++) {
 			double mn = std::min(v0[a], std::min(v1[a], v2[a])), mx = std::max(v0[a], std::max(v1[a], v2[a]));
-			bx.lo[a] = round_down(mn);
-			bx.hi[a] = round_up(mx);
+			bx.lo[a] = round_down(rlo[a]);
+			bx.hi[a] = round_up(rhi[a]);
 			b.centroid[3 * t + a] = (float)(0.5 * (mn + mx));
 		}
 		b.prim_box[t] = bx;

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdint>
 #include <string>
+#include "accept_region.h"
 #include "bvh_builder.h"
 #include "device_build.h"
 #include "trace.h"
@@ -64,14 +65,16 @@ __global__ void __launch_bounds__(kBlock) k_tri_boxes(const double2 *__restrict_
 {
 	float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
 	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-		const double2 a0 = tri_a[3 * (size_t)i], a1 = tri_a[3 * (size_t)i + 1];
+		const double2 a0 = tri_a[3 * (size_t)i], a1 = tri_a[3 * (size_t)i + 1], a2 = tri_a[3 * (size_t)i + 2];
 		const double2 b0 = tri_b[3 * (size_t)i], b1 = tri_b[3 * (size_t)i + 1], b2 = tri_b[3 * (size_t)i + 2];
-		const double vx[3] = {a0.x, b0.x, b1.y}, vy[3] = {a0.y, b0.y, b2.x}, vz[3] = {a1.x, b1.x, b2.y};
+		// the box of everything the reference's test of this fan triangle can accept: the vertices' box for a planar polygon, more
+		// for a polygon that is not (accept_region.h)
+		const double v0[3] = {a0.x, a0.y, a1.x}, nf[3] = {a1.y, a2.x, a2.y}, v1[3] = {b0.x, b0.y, b1.x}, v2[3] = {b1.y, b2.x, b2.y};
+		double rlo[3], rhi[3];
+		accept_region_box(v0, v1, v2, nf, rlo, rhi);
 		Box4 b;
-		b.lo = make_float4(__double2float_rd(fmin(fmin(vx[0], vx[1]), vx[2])), __double2float_rd(fmin(fmin(vy[0], vy[1]), vy[2])),
-		                   __double2float_rd(fmin(fmin(vz[0], vz[1]), vz[2])), 0.0f);
-		b.hi = make_float4(__double2float_ru(fmax(fmax(vx[0], vx[1]), vx[2])), __double2float_ru(fmax(fmax(vy[0], vy[1]), vy[2])),
-		                   __double2float_ru(fmax(fmax(vz[0], vz[1]), vz[2])), 0.0f);
+		b.lo = make_float4(__double2float_rd(rlo[0]), __double2float_rd(rlo[1]), __double2float_rd(rlo[2]), 0.0f);
+		b.hi = make_float4(__double2float_ru(rhi[0]), __double2float_ru(rhi[1]), __double2float_ru(rhi[2]), 0.0f);
 		boxes[i] = b;
 		const float cx = 0.5f * (b.lo.x + b.hi.x), cy = 0.5f * (b.lo.y + b.hi.y), cz = 0.5f * (b.lo.z + b.hi.z);
 		clo[0] = fminf(clo[0], cx); chi[0] = fmaxf(chi[0], cx);

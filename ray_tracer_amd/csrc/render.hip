@@ -23,6 +23,7 @@
 #include <utility>
 #include <thread>
 #include <vector>
+#include "accept_region.h"
 #include "parallel_for.h"
 #include "render.h"
 #include "trace.h"
@@ -1454,12 +1455,19 @@ hipError_t render_upload_materials(RenderState &rs, const HostScene &host, const
 	for (size_t l = 0; l < light_faces.size(); l++) {
 		const uint32_t f = light_faces[l];
 		double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX}, big = 0.0;
-		for (uint64_t c = host.face_begin[f]; c < host.face_begin[f + 1]; c++)
+		// everything the reference's test can accept as a hit on this polygon: for a polygon that is not planar that is more than
+		// the box of its vertices (accept_region.h)
+		for (uint64_t t = host.tri_begin[f]; t < host.tri_begin[f + 1]; t++) {
+			const double *v0, *v1, *v2;
+			host.tri_vertices(t, v0, v1, v2);
+			double rlo[3], rhi[3];
+			accept_region_box(v0, v1, v2, &host.face_normal[3 * (size_t)f], rlo, rhi);
 			for (int a = 0; a < 3; a++) {
-				lo[a] = std::min(lo[a], host.pv[3 * c + a]);
-				hi[a] = std::max(hi[a], host.pv[3 * c + a]);
-				big = std::max(big, std::fabs(host.pv[3 * c + a]));
+				lo[a] = std::min(lo[a], rlo[a]);
+				hi[a] = std::max(hi[a], rhi[a]);
+				big = std::max(big, std::max(std::fabs(rlo[a]), std::fabs(rhi[a])));
 			}
+		}
 		float flo[3], fhi[3];
 		for (int a = 0; a < 3; a++) {
 			flo[a] = std::nextafter((float)lo[a], -FLT_MAX);

@@ -109,8 +109,8 @@ def _material_json(name, node_type, light=False, **arrays):
 
 def atrium(directory, detail=1.0, seed=7):
     """Writes a hall-like project (model.obj, materials.json, objmatmap.json) into `directory` and returns their paths and the
-    polygon count.  At detail 1: 31 objects, about 380 k polygons (110 k planar quads, 270 k triangles; 490 k fan triangles): a displaced
-    floor and side walls (triangles), flat walls and ceiling (quads), two rows of fluted columns (quads), displaced spheres (triangles)
+    polygon count.  At detail 1: 31 objects, about 320 k polygons (170 k quads, of which 58 k are not planar, 150 k triangles; 490 k fan
+    triangles): a displaced floor and side walls (quads that are not planar), flat walls and ceiling (quads), two rows of fluted columns (quads), displaced spheres (triangles)
     of glass, metal and paint, and six ceiling light panels of two quads each.  Smooth vertex normals everywhere (every corner carries a vn index)."""
     import json
     import os
@@ -130,12 +130,9 @@ def atrium(directory, detail=1.0, seed=7):
         h = bump * (np.sin(17 * u + 3 * v) * np.cos(13 * v) + 0.3 * np.sin(71 * u * v))
         p = origin + u[..., None] * eu + v[..., None] * ev + h[..., None] * nrm
         du, dv = np.gradient(p, axis=1), np.gradient(p, axis=0)
+        # quads also where the sheet is displaced: such a cell is not planar, and the reference intersects both of its fan triangles
+        # with the plane of its first three vertices (object.cpp:244), as a modelled scene's slightly warped quads are
         faces = _grid_quads(nu, nv, False)
-        if bump != 0.0:
-            # a displaced cell is not planar, and the reference intersects every fan triangle of a polygon with the plane of the
-            # polygon's first three vertices (object.cpp:244): such a "hit" can lie outside the polygon's bounding box, and whether
-            # a tree finds it depends on its topology.  Displaced sheets are therefore triangles; quads stay where they are flat.
-            faces = np.concatenate([faces[:, [0, 1, 2]], faces[:, [0, 2, 3]]])
         add(name, material, p.reshape(-1, 3), np.cross(du, dv).reshape(-1, 3), faces)
 
     g = max(8, int(140 * np.sqrt(detail)))

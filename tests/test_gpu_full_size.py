@@ -197,7 +197,7 @@ def test_scan_sized_ply_object_full_hd(tmp_path):
 
 
 def test_large_obj_project_4k(tmp_path):
-    """A multi-object OBJ project of modelled-scene size (about 380 k polygons: planar quads and triangles, 31 objects, 12 light polygons, all five
+    """A multi-object OBJ project of modelled-scene size (about 320 k polygons: quads, 58 k of them not planar, and triangles; 31 objects, 12 light polygons, all five
     BSDF node types; procedural, written to disk) loaded through Renderer.Load + LoadMaterials and rendered at 3840x2160 with 30 bands"""
     from ray_tracer_amd import scene_io
     from ray_tracer_amd.renderer import Renderer, MIS

@@ -81,6 +81,58 @@ def test_two_ranks_on_one_gpu_sum_to_the_single_context_film(tmp_path):
     assert np.allclose(got, whole, rtol=1e-4, atol=1e-8)
 
 
+RAY_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ray_tracer_amd import capi, synth
+n_tri, m = int(sys.argv[3]), int(sys.argv[4])
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+ctx = capi.Context(0)
+ctx.upload_mesh(synth.soup(n_tri, 0.01, seed=12345))       # every rank holds a replica of the scene
+rays = synth.incoherent_rays(m, seed=777, start=rank * m)  # and traces its own range of the ray sequence: no exchange step
+d_rays = torch.from_numpy(rays).cuda()
+d_hits = torch.empty((m, 4), dtype=torch.int32, device="cuda")
+d_t64 = torch.empty(m, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr(), d_t64.data_ptr())
+ctx.render_sync()
+np.savez(sys.argv[2] + ".%d.npz" % rank, hits=d_hits.cpu().numpy(), t64=d_t64.cpu().numpy())
+dist.barrier()
+ctx.close()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_trace_their_ray_ranges_of_one_sequence(tmp_path):
+    """the traversal benchmark's sharding (bench.py's soup legs at --gpus N): rank r traces rays [r M, (r + 1) M) of the counter-based
+    ray sequence on its own replica of the scene; the two ranks' hits and fp64 t are the matching halves of one context's trace of
+    rays [0, 2 M)"""
+    n_tri, m = 120000, 300001
+    worker = tmp_path / "ray_worker.py"
+    worker.write_text(RAY_WORKER)
+    out = tmp_path / "hits"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", str(worker), ROOT, str(out), str(n_tri), str(m)]
+    subprocess.run(cmd, check=True, env=env, timeout=280, cwd=str(tmp_path))
+    from ray_tracer_amd import synth
+    ctx = capi.Context(0)
+    ctx.upload_mesh(synth.soup(n_tri, 0.01, seed=12345))
+    hits, t64 = ctx.trace_closest(synth.incoherent_rays(2 * m, seed=777), want_t64=True)
+    ctx.close()
+    assert (hits["prim"] != capi.MISS).sum() > m // 2
+    for rank in range(2):
+        got = np.load(str(out) + ".%d.npz" % rank)
+        part = hits[rank * m:(rank + 1) * m]
+        assert np.array_equal(got["hits"].view(np.uint32)[:, 1], part["prim"]) and np.array_equal(got["hits"].view(np.uint32)[:, 2], part["tri"])
+        assert np.array_equal(got["t64"], t64[rank * m:(rank + 1) * m])
+
+
 def test_group_of_contexts_renders_the_single_context_film():
     """rt_group_*: three contexts (all on device 0 here; one per GPU on a node) split every pass's samples; the summed film and its
     tonemap equal a single context's, for the unidirectional and the bidirectional integrator, in one pass or many"""

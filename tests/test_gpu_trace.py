@@ -351,38 +351,153 @@ def test_rays_ordered_by_cell_give_the_same_answers(ctx, builder, monkeypatch):
     assert a0.sum() > 10000 and np.array_equal(a0, a1)
 
 
-def test_ordered_batches_on_two_streams_do_not_share_buffers_at_once(ctx, monkeypatch):
+def polygon_mesh(polys):
+    """rt_mesh tables of one object from a list of polygons (each an [k, 3] array), one flat normal per polygon"""
+    v = np.concatenate(polys).astype(np.float64)
+    counts = np.array([len(p) for p in polys])
+    begin = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    nrm = np.array([np.cross(p[1] - p[0], p[2] - p[1]) for p in polys])
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-300)
+    idx = np.arange(len(v), dtype=np.int64)
+    corners = np.stack([idx, np.full(len(v), -1, dtype=np.int64), np.repeat(np.arange(len(polys)), counts)], axis=1)
+    return {"v": v, "vt": np.zeros((0, 3)), "vn": nrm, "corners": corners, "face_begin": begin,
+            "object_begin": np.array([0, len(polys)], dtype=np.uint64), "names": ["warped"]}
+
+
+def warped_scene(seed):
+    """sheets of quads displaced out of their plane by 1e-6 ... 1e-1 of an edge, and pentagons / octagons (fan triangles with obtuse
+    corners) whose vertices are moved off their plane: polygons for which the reference's test (every fan triangle on the plane of
+    the polygon's first three vertices, object.cpp:244) accepts points outside the fan triangle and outside its vertices' box"""
+    rng = np.random.default_rng(seed)
+    polys = []
+    n = 40
+    for level, dev in enumerate([1e-6, 1e-4, 1e-2, 1e-1]):
+        u, w = np.meshgrid(np.linspace(-1, 1, n + 1), np.linspace(-1, 1, n + 1), indexing="ij")
+        edge = 2.0 / n
+        y = -0.75 + 0.5 * level + dev * edge * rng.normal(size=u.shape)
+        p = np.stack([u, y, w], -1)
+        for i in range(n):
+            for j in range(n):
+                polys.append(np.array([p[i, j], p[i + 1, j], p[i + 1, j + 1], p[i, j + 1]]))
+    for k in range(1500):
+        m = int(rng.choice([5, 8]))
+        c, r = rng.uniform(-0.9, 0.9, 3), rng.uniform(0.02, 0.12)
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, m))  # irregular: some fan triangles are slivers
+        ring = np.stack([np.cos(ang), np.sin(ang), 10.0 ** rng.uniform(-5, -0.7) * rng.normal(size=m)], -1) * r
+        polys.append(c + ring @ q.T)
+    return polygon_mesh(polys)
+
+
+@pytest.mark.parametrize("builder", [capi.BUILDER_HOST_SAH, capi.BUILDER_DEVICE_LBVH])
+def test_polygons_that_are_not_planar_have_the_brute_force_answer(ctx, builder):
+    """For a polygon that is not planar the hit point of a later fan triangle need not lie in that triangle's box.  The builders box
+    everything the reference's test can accept (accept_region.h), so whatever the tree and whatever the order in which waves prune,
+    the closest hit is the one a loop over all polygons finds (HittableList::Hit, hittablelist.cpp:3-17): ids and fp64 t equal to
+    the oracle's brute-force loop, for either builder, twice in a row, and for the any-hit query."""
+    mesh = warped_scene(17)
+    sc = oracle.Scene(mesh)
+    rng = np.random.default_rng(5)
+    rays = synth.incoherent_rays(60000, seed=23)
+    graze = synth.incoherent_rays(40000, seed=24)  # nearly parallel to the sheets: long walks just above and below them
+    graze[:, 5] *= 0.02
+    aimed = synth.incoherent_rays(20000, seed=25)  # towards points next to the corners of the many-sided polygons
+    v = mesh["v"]
+    target = v[rng.integers(4 * 40 * 40 * 4, len(v), len(aimed))]  # corners of the many-sided polygons (they follow the four sheets) + rng.normal(size=(len(aimed), 3)) * 0.01
+    aimed[:, 4:7] = (target - aimed[:, 0:3]).astype(np.float32)
+    rays = np.concatenate([rays, graze, aimed])
+    o_poly, o_tri, o_t = sc.trace_closest(rays, oracle.MODE_LIST_LOWEST)
+    assert (o_poly >= 0).mean() > 0.5
+    ctx.set_builder(builder)
+    runs = []
+    for rep in range(2):
+        ctx.upload_mesh(mesh)
+        hits, t64 = ctx.trace_closest(rays, want_t64=True)
+        gp = hits["prim"].astype(np.int64)
+        gp[hits["prim"] == capi.MISS] = -1
+        assert np.array_equal(t64, o_t), "t differs from the loop over all polygons on %d rays" % (t64 != o_t).sum()
+        assert (gp != o_poly).sum() <= 2  # exact ties in t between neighbours
+        runs.append((hits.copy(), t64.copy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    # the oracle's distance-ordered, pruning walk of the same tree agrees as well: the boxes hold the hits
+    wn, wt = ctx.wide_bvh()
+    w_poly, _, w_t, _, _ = sc.trace_wide(wn, wt, rays)
+    assert np.array_equal(w_t, o_t)
+    short = rays.copy()
+    short[:, 7] = 0.4
+    assert np.array_equal(ctx.trace_any(short), sc.trace_any(short, oracle.MODE_LIST))
+    ctx.set_builder(capi.BUILDER_AUTO)
+    # and the hits outside the vertices' boxes exist in this scene: the brute-force loop finds hit points that lie outside the box
+    # of the fan triangle they are reported for
+    hit = o_tri >= 0
+    p = rays[hit, 0:3].astype(np.float64) + o_t[hit, None] * rays[hit, 4:7].astype(np.float64)
+    tri_v = fan_triangle_vertices(mesh, o_tri[hit])
+    lo, hi = tri_v.min(1) - 1e-7, tri_v.max(1) + 1e-7
+    assert (np.any((p < lo) | (p > hi), axis=1)).sum() > 0
+
+
+def fan_triangle_vertices(mesh, tri):
+    """[n, 3, 3] vertices of fan triangles given by their index in polygon order"""
+    begin = mesh["face_begin"].astype(np.int64)
+    counts = np.diff(begin) - 2
+    tri_begin = np.concatenate([[0], np.cumsum(counts)])
+    face = np.searchsorted(tri_begin, tri, side="right") - 1
+    k = tri - tri_begin[face]
+    v = mesh["v"]
+    return np.stack([v[begin[face]], v[begin[face] + k + 1], v[begin[face] + k + 2]], axis=1)
+
+
+TWO_STREAMS_WORKER = r"""
+import os, sys
+import numpy as np
+import torch  # before the library: the wheel's HIP runtime has to be the one both use
+sys.path.insert(0, sys.argv[1])
+from ray_tracer_amd import capi, synth
+ctx = capi.Context(0)
+ctx.upload_mesh(synth.soup(200000, 0.01, seed=5))
+n = 1 << 21
+ra, rb = synth.incoherent_rays(n, seed=91), synth.incoherent_rays(n, seed=92)
+da, db = torch.from_numpy(ra).cuda(), torch.from_numpy(rb).cuda()
+want = []
+os.environ["MI355RT_RAY_BINS"] = "0"
+for d in (da, db):
+    h = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+    t = torch.empty(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.trace_closest_device(d.data_ptr(), n, h.data_ptr(), t.data_ptr())
+    ctx.render_sync()
+    want.append((h.cpu().numpy(), t.cpu().numpy()))
+assert not np.array_equal(want[0][0], want[1][0])
+assert (want[0][0][:, 1] != -1).sum() > n // 4
+os.environ["MI355RT_RAY_BINS"] = "1"
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+for rep in range(3):
+    ha, hb = torch.zeros((n, 4), dtype=torch.int32, device="cuda"), torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    ta, tb = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.trace_closest_device(da.data_ptr(), n, ha.data_ptr(), ta.data_ptr(), stream=s1.cuda_stream)
+    ctx.trace_closest_device(db.data_ptr(), n, hb.data_ptr(), tb.data_ptr(), stream=s2.cuda_stream)
+    ctx.trace_closest_device(da.data_ptr(), n, ha.data_ptr(), ta.data_ptr(), stream=s1.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(ha.cpu().numpy(), want[0][0]) and np.array_equal(ta.cpu().numpy(), want[0][1]), rep
+    assert np.array_equal(hb.cpu().numpy(), want[1][0]) and np.array_equal(tb.cpu().numpy(), want[1][1]), rep
+ctx.close()
+print("two streams ok")
+"""
+
+
+def test_ordered_batches_on_two_streams_do_not_share_buffers_at_once(tmp_path):
     """Two ordered batches of one context enqueued back to back on two different streams, without a host wait between them: the
     ordering goes through buffers that belong to the context, so the second batch must wait (on the device) until the first one's
-    results are out.  Both must equal the unordered answers."""
-    import torch
-    mesh = synth.soup(200000, 0.01, seed=5)
-    ctx.upload_mesh(mesh)
-    n = 1 << 21
-    ra, rb = synth.incoherent_rays(n, seed=91), synth.incoherent_rays(n, seed=92)
-    da, db = torch.from_numpy(ra).cuda(), torch.from_numpy(rb).cuda()
-    want = []
-    monkeypatch.setenv("MI355RT_RAY_BINS", "0")
-    for d in (da, db):
-        h = torch.empty((n, 4), dtype=torch.int32, device="cuda")
-        t = torch.empty(n, dtype=torch.float64, device="cuda")
-        torch.cuda.synchronize()
-        ctx.trace_closest_device(d.data_ptr(), n, h.data_ptr(), t.data_ptr())
-        ctx.render_sync()
-        want.append((h.cpu().numpy(), t.cpu().numpy()))
-    assert not np.array_equal(want[0][0], want[1][0])
-    monkeypatch.setenv("MI355RT_RAY_BINS", "1")
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    for rep in range(3):
-        ha, hb = torch.zeros((n, 4), dtype=torch.int32, device="cuda"), torch.zeros((n, 4), dtype=torch.int32, device="cuda")
-        ta, tb = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")
-        torch.cuda.synchronize()
-        ctx.trace_closest_device(da.data_ptr(), n, ha.data_ptr(), ta.data_ptr(), stream=s1.cuda_stream)
-        ctx.trace_closest_device(db.data_ptr(), n, hb.data_ptr(), tb.data_ptr(), stream=s2.cuda_stream)
-        ctx.trace_closest_device(da.data_ptr(), n, ha.data_ptr(), ta.data_ptr(), stream=s1.cuda_stream)
-        torch.cuda.synchronize()
-        assert np.array_equal(ha.cpu().numpy(), want[0][0]) and np.array_equal(ta.cpu().numpy(), want[0][1])
-        assert np.array_equal(hb.cpu().numpy(), want[1][0]) and np.array_equal(tb.cpu().numpy(), want[1][1])
+    results are out.  Both must equal the unordered answers.  In a process of its own: the streams and device buffers are
+    PyTorch's, and a process that uses PyTorch has to import it before the library is loaded."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = tmp_path / "two_streams.py"
+    worker.write_text(TWO_STREAMS_WORKER)
+    out = subprocess.run([sys.executable, str(worker), root], capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "two streams ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_host_buffer_batch_in_parts(ctx):

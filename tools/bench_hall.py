@@ -1,4 +1,4 @@
-"""Auxiliary measurement for the large-OBJ configuration: the procedural hall (about 380 k polygons, 31 objects, 12 light polygons, all
+"""Auxiliary measurement for the large-OBJ configuration: the procedural hall (about 320 k polygons, 31 objects, 12 light polygons, all
 BSDF types; ray_tracer_amd/synth.py) at 3840x2160, NEE+MIS, in passes of one queue batch.  Prints one JSON line.
 usage: python tools/bench_hall.py [--spp 32] [--algorithm mis]"""
 import argparse, json, os, sys, tempfile, time
