@@ -11,11 +11,13 @@ sample indices of the same image (weak scaling: K steps per rank) into its own f
 are summed with one RCCL all-reduce inside the timed region.
 
 The JSON line also carries
-  roofline      for the dominant kernel (closest-hit traversal): `achieved` = bytes that crossed the memory side of the L2 per launch
-                (rocprofv3 PMC passes over this same command, committed under profiles/) over the kernel's average duration measured
-                here with HIP events on its stream inside the timed region, against 8 TB/s; `algorithmic` prices the same launches by
-                work units counted on the CPU (nodes fetched and triangle records tested in the 8-wide tree the kernel walks, and the
-                binary-tree formula 32 + 16 + 64 * nodes + 48 * triangles next to it); `limiter` says what actually bounds the kernel;
+  roofline      for the dominant kernel (closest-hit traversal).  On this cache-resident scene the kernel is bound by its own vector
+                instruction stream: `frac` = the time its instructions take at the chip's sustained issue rate for its mix
+                (tools/calib/valu_issue_rate, profiles/r03_valu_issue_rate.txt; instruction counts from rocprofv3 PMC passes over
+                this same command, committed under profiles/) over the kernel's time measured here with HIP events on its stream;
+                `hbm` / `frac_hbm` = the measured bytes on the memory side of the L2 per step over the kernel's time per step,
+                against 8 TB/s; `algorithmic` prices the same launches by work units counted on the CPU (nodes fetched and triangle
+                records tested in the 8-wide tree the kernel walks, and the binary-tree formula 32 + 16 + 64 * nodes + 48 * triangles);
   cpu_baseline  the fp64 CPU restatement of the reference renderer (oracle/) timed on this host's cores on a bounded sample of the
                 same workload;
   aux           the incoherent closest-hit rate on the 1M- and 10M-triangle random soups, each with its own traffic figures.
@@ -33,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # bytes/s
+PROFILE_STEPS = 18  # steps of the command the committed PMC profile was taken over (python bench.py --no-cpu --no-soup: 2 warm-up + 16 timed)
 
 
 # the closest-hit kernel's instantiations (stack in LDS or in scratch; reference triangle test; cache-resident scene or not) as
@@ -57,14 +60,17 @@ def recorded_traffic(pattern, kernels):
 
 
 def recorded_counters(pattern, kernel):
-    """what the committed PMC summary says about `kernel` besides traffic: lane utilisation of its vector instructions, the share
-    of wave time spent issuing them, and the share spent waiting (tools/traffic_from_profile.py); None when there is none"""
+    """what the committed PMC summary says about `kernel` besides traffic: vector instructions per launch (all, and the fp64 ones), the
+    sustained issue rates they are priced at, lane utilisation, the share of wave time spent issuing them and the share spent
+    waiting (tools/traffic_from_profile.py); None when there is none"""
     k, f = recorded_traffic(pattern, kernel)
     if not k or "valu_lane_utilization" not in k:
         return None
-    return {"valu_busy": k.get("valu_busy"), "valu_lane_utilization": k["valu_lane_utilization"],
-            "valu_issue_share_of_wave_time": k["valu_issue_share_of_wave_time"], "wait_share_of_wave_time": k["wait_share_of_wave_time"],
-            "l2_hit_rate": k.get("l2_hit_rate"), "source": f}
+    out = {name: k.get(name) for name in ("valu_instructions_per_launch", "valu_f64_instructions_per_launch", "valu_issue_rates", "valu_lane_utilization",
+                                          "valu_issue_share_of_wave_time", "wait_share_of_wave_time", "wait_inst_share_of_wave_time", "l2_hit_rate")}
+    out["valu_issue_frac_in_profile"] = k.get("valu_issue_frac")
+    out["source"] = f
+    return out
 
 
 def b_ray_wide(nodes_per_ray, tris_per_ray, tri_record_bytes):
@@ -397,22 +403,42 @@ def main():
     if rank == 0:
         k = prof["closest"]
         avg_ms = k["ms"] / max(k["launches"], 1)
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "k_trace (closest hit)", "kernel_ms_avg": avg_ms, "launches": k["launches"],
-                "rays": k["items"], "kernel_ms_total": k["ms"], "mrays_per_s_in_kernel": k["items"] / max(k["ms"], 1e-9) / 1e3}
+        # What binds the dominant kernel on this scene is its own instruction stream, not HBM (tree and triangles live in the caches):
+        # `frac` is the time the kernel's vector instructions would take at the sustained issue rate of this chip for its own mix
+        # (tools/calib/valu_issue_rate: the box-test mix and the fp64 mix at 4 waves per SIMD, the kernel's occupancy) over the time
+        # the kernel took in this run.  The HBM figures stay beside it (`hbm`): measured bytes per step over the kernel's time per step.
+        launches_per_step = k["launches"] / max(args.steps, 1)
+        ms_per_step_in_kernel = k["ms"] / max(args.steps, 1)
+        roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
+                "kernel": "k_trace (closest hit)", "kernel_ms_avg": avg_ms, "launches": k["launches"], "launches_per_step": launches_per_step,
+                "kernel_ms_per_step": ms_per_step_in_kernel, "rays": k["items"], "kernel_ms_total": k["ms"],
+                "mrays_per_s_in_kernel": k["items"] / max(k["ms"], 1e-9) / 1e3}
         default_workload = (nx, ny, spp, args.algorithm) == (1920, 1080, 64, "mis")
         tr, tr_file = recorded_traffic("r*_bench_traffic.json", CLOSEST_KERNELS)
         if tr is not None and default_workload:
+            # per step, so that the number of launches the profile averaged over and the number timed here cannot disagree: the
+            # profile's bytes per ray times the rays of a step here, over the kernel's time per step here
+            bytes_per_step = tr["bytes_per_launch"] * tr["dispatches"] / PROFILE_STEPS
             roof["traffic"] = tr["bytes_per_launch"]
-            roof["achieved"] = tr["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
-            roof["frac"] = roof["achieved"] * 1e9 / HBM_PEAK
-            roof["traffic_note"] = ("bytes per launch on the memory side of the L2 (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes over "
-                                    "this command, recorded in %s) over the launch duration measured in this run: the tree and the triangles of "
-                                    "this scene stay in the caches, only rays and hits reach HBM" % tr_file)
+            roof["hbm"] = {"bound": "hbm", "bytes_per_step": bytes_per_step, "achieved": bytes_per_step / (ms_per_step_in_kernel * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                           "unit": "GB/s", "note": "bytes on the memory side of the L2 (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes over this command, %s), "
+                                                   "summed over the profiled run's %d steps and divided by them, over the kernel's time per step in this run: only rays and hits "
+                                                   "reach HBM on this scene" % (tr_file, PROFILE_STEPS)}
+            roof["hbm"]["frac"] = roof["hbm"]["achieved"] * 1e9 / HBM_PEAK
+            roof["frac_hbm"] = roof["hbm"]["frac"]
             lim = recorded_counters("r*_bench_traffic.json", CLOSEST_KERNELS)
-            if lim is not None:
-                roof["limiter"] = dict(lim, what="vector instruction issue, not memory (the scene is cache resident): valu_busy is the share of SIMD time spent "
-                                                  "issuing vector instructions, valu_lane_utilization the share of their lanes that did work")
+            if lim is not None and lim.get("valu_issue_rates"):
+                rates = lim["valu_issue_rates"]
+                n_all = lim["valu_instructions_per_launch"] * tr["dispatches"] / PROFILE_STEPS  # vector instructions of one step
+                n_f64 = lim["valu_f64_instructions_per_launch"] * tr["dispatches"] / PROFILE_STEPS
+                issue_seconds = (n_all - n_f64) / rates["node"] + n_f64 / rates["f64"]
+                roof["achieved"] = n_all / (ms_per_step_in_kernel * 1e-3) / 1e9
+                roof["peak"] = n_all / issue_seconds / 1e9  # the sustained rate for this kernel's mix of fp32 and fp64 instructions
+                roof["frac"] = issue_seconds / (ms_per_step_in_kernel * 1e-3)
+                roof["limiter"] = dict(lim, what="the kernel's own vector instruction stream: frac = time its instructions take at the sustained issue rate (box-test mix %.0f G/s, "
+                                                 "fp64 mix %.0f G/s at 4 waves per SIMD) over the time it took; the rest is latency the four waves per SIMD do not cover "
+                                                 "(wait_inst_share_of_wave_time: share of wave time spent waiting for a memory instruction to return)"
+                                                 % (rates["node"] / 1e9, rates["f64"] / 1e9))
         counts = None
         if cpu is not None:
             counts = dict(cpu, source="counted in this run")

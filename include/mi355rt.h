@@ -288,6 +288,12 @@ int rt_group_render_pass(rt_group *g, int first_sample, int n_samples);
 int rt_group_render_sync(rt_group *g);
 int rt_group_download_film(rt_group *g, double *spectrum_img);                       /* the sum of the member films */
 int rt_group_download_preview(rt_group *g, int samples_done, double *preview_img);   /* tonemap of that sum */
+/* milliseconds the last gather-and-sum of the member films took on the first member's GPU (peer copies of all members at once,
+ * each over its own xGMI link, and one summing kernel); 0 before the first download */
+double rt_group_last_sum_ms(const rt_group *g);
+/* the traversal benchmark on a group (replaces the loop of renderer.cpp:74-77 for rays instead of pixels): member i answers the
+ * i-th of n contiguous ranges of `rays` on its own replica of the scene; arguments and results as rt_trace_closest */
+int rt_group_trace_closest(rt_group *g, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64);
 
 /* ---- introspection (tests, roofline accounting) ---- */
 /* Per-kernel device time measured with HIP events recorded on the stream each kernel is launched on.

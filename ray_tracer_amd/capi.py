@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_group_create", "rt_group_destroy", "rt_group_last_error", "rt_group_size", "rt_group_context", "rt_group_upload_mesh",
     "rt_group_upload_materials", "rt_group_upload_material_graphs", "rt_group_set_environment", "rt_group_set_camera", "rt_group_clear",
     "rt_group_render_begin", "rt_group_render_pass", "rt_group_render_sync", "rt_group_download_film", "rt_group_download_preview",
-    "rt_get_stats", "rt_get_bvh2", "rt_get_wide_bvh", "rt_filter_bilateral", "rt_filter_bilateral_device", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays", "rt_accept_region_box",
+    "rt_get_stats", "rt_get_bvh2", "rt_get_wide_bvh", "rt_filter_bilateral", "rt_filter_bilateral_device", "rt_stream", "rt_profile_start", "rt_profile_stop", "rt_render_capture_rays", "rt_accept_region_box", "rt_group_last_sum_ms", "rt_group_trace_closest",
 ]
 
 RAY_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("oz", "f4"), ("tmin", "f4"),
@@ -157,6 +157,9 @@ def load():
     lib.rt_group_render_sync.argtypes = [vp]
     lib.rt_group_download_film.argtypes = [vp, vp]
     lib.rt_group_download_preview.argtypes = [vp, i32, vp]
+    lib.rt_group_last_sum_ms.argtypes = [vp]
+    lib.rt_group_last_sum_ms.restype = C.c_double
+    lib.rt_group_trace_closest.argtypes = [vp, vp, u64, vp, vp]
     _lib = lib
     return lib
 
@@ -486,3 +489,17 @@ class Group:
         out = np.zeros((nx * ny, 3), dtype=np.float64)
         self._check(self.lib.rt_group_download_preview(self.h, samples_done, _ptr(out)))
         return out
+
+    def last_sum_ms(self):
+        """milliseconds the last gather-and-sum of the member films took on the first member's GPU"""
+        return float(self.lib.rt_group_last_sum_ms(self.h))
+
+    def trace_closest(self, rays, want_t64=False):
+        """member i answers the i-th contiguous range of the rays on its own replica of the scene"""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = len(rays)
+        hits = np.zeros(n, dtype=HIT_DTYPE)
+        t64 = np.zeros(n, dtype=np.float64) if want_t64 else None
+        self._check(self.lib.rt_group_trace_closest(self.h, _ptr(rays), n, _ptr(hits), _ptr(t64) if want_t64 else None))
+        return (hits, t64) if want_t64 else hits
+

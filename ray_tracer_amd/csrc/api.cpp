@@ -853,8 +853,11 @@ void *rt_stream(rt_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 struct rt_group {
 	std::vector<rt_context *> members;
-	float *d_sum = nullptr, *d_stage = nullptr; // on the first member's device: the summed film, and one member film in transit
-	size_t sum_elems = 0;
+	// on the first member's device: the summed film, and one slice per member on another device for its film in transit
+	float *d_sum = nullptr, *d_stage = nullptr;
+	size_t sum_elems = 0, stage_slices = 0;
+	std::vector<hipEvent_t> arrived; // per member: its film has reached its slice (created on first use, on the member's device)
+	double last_sum_ms = 0.0;        // how long the last gather and sum took, on the first member's stream
 	std::string error;
 };
 
@@ -911,33 +914,60 @@ int group_fail(rt_group *g, int code, const std::string &msg)
 	return code;
 }
 
-// sums the member films into g->d_sum on the first member's device; every member must have finished (rt_render_sync)
+// Sums the member films into g->d_sum on the first member's device; every member must have finished (rt_render_sync).
+// Every member on another device pushes its film over its own xGMI link into a slice of its own on the first member's device, on
+// its own stream, all at the same time (the links are point to point: seven copies in turn would use one link at a time); the
+// first member's stream waits for the arrivals and one kernel adds all films up.  Members on the first member's device are read
+// where they lie.
 int group_sum_films(rt_group *g)
 {
 	rt_context *root = g->members[0];
 	if (!root->render.begun) return group_fail(g, RT_ERR_INVALID, "rt_group: nothing rendered");
 	const size_t elems = (size_t)root->render.nx * root->render.ny * RT_NBINS, bytes = elems * sizeof(float);
+	size_t remote = 0;
+	for (rt_context *m : g->members) remote += m->device != root->device ? 1 : 0;
 	hipError_t e = hipSetDevice(root->device);
-	if (e == hipSuccess && g->sum_elems != elems) {
+	if (e == hipSuccess && (g->sum_elems != elems || g->stage_slices < remote)) {
 		if (g->d_sum) (void)hipFree(g->d_sum);
 		if (g->d_stage) (void)hipFree(g->d_stage);
 		g->d_sum = g->d_stage = nullptr;
-		g->sum_elems = 0;
+		g->sum_elems = g->stage_slices = 0;
 		e = hipMalloc((void **)&g->d_sum, bytes);
-		if (e == hipSuccess && g->members.size() > 1) e = hipMalloc((void **)&g->d_stage, bytes);
-		if (e == hipSuccess) g->sum_elems = elems;
+		if (e == hipSuccess && remote) e = hipMalloc((void **)&g->d_stage, bytes * remote);
+		if (e == hipSuccess) { g->sum_elems = elems; g->stage_slices = remote; }
 	}
-	if (e == hipSuccess) e = hipMemcpyAsync(g->d_sum, root->render.d_film, bytes, hipMemcpyDeviceToDevice, root->stream);
-	for (size_t i = 1; i < g->members.size() && e == hipSuccess; i++) {
+	if (g->arrived.size() < g->members.size()) g->arrived.resize(g->members.size(), nullptr);
+	hipEvent_t t0 = nullptr, t1 = nullptr;
+	if (e == hipSuccess) e = hipEventCreate(&t0);
+	if (e == hipSuccess) e = hipEventCreate(&t1);
+	if (e == hipSuccess) e = hipEventRecord(t0, root->stream);
+	const float *src[kMaxFilmSources];
+	size_t n_src = 0, slice = 0;
+	for (size_t i = 0; i < g->members.size() && e == hipSuccess; i++) {
 		rt_context *m = g->members[i];
-		if (m->device == root->device) e = render_accumulate_film(g->d_sum, m->render.d_film, elems, root->stream);
-		else {
-			e = hipMemcpyPeerAsync(g->d_stage, root->device, m->render.d_film, m->device, bytes, root->stream);
-			if (e == hipSuccess) e = render_accumulate_film(g->d_sum, g->d_stage, elems, root->stream);
-		}
+		if (m->device == root->device) { src[n_src++] = m->render.d_film; continue; }
+		float *dst = g->d_stage + slice++ * elems;
+		e = hipSetDevice(m->device); // the copy is the sender's: it goes on the member's stream, behind the member's rendering
+		if (e == hipSuccess && !g->arrived[i]) e = hipEventCreateWithFlags(&g->arrived[i], hipEventDisableTiming);
+		if (e == hipSuccess) e = hipMemcpyPeerAsync(dst, root->device, m->render.d_film, m->device, bytes, m->stream);
+		if (e == hipSuccess) e = hipEventRecord(g->arrived[i], m->stream);
+		if (e == hipSuccess) e = hipSetDevice(root->device);
+		if (e == hipSuccess) e = hipStreamWaitEvent(root->stream, g->arrived[i], 0);
+		src[n_src++] = dst;
 	}
+	(void)hipSetDevice(root->device);
+	if (e == hipSuccess) e = render_sum_films(g->d_sum, src, n_src, elems, root->stream);
+	if (e == hipSuccess) e = hipEventRecord(t1, root->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(root->stream);
-	if (e != hipSuccess) return group_fail(g, RT_ERR_HIP, std::string("rt_group: summing the member films: ") + hipGetErrorString(e));
+	float ms = 0.0f;
+	if (e == hipSuccess && hipEventElapsedTime(&ms, t0, t1) == hipSuccess) g->last_sum_ms = ms;
+	if (t0) (void)hipEventDestroy(t0);
+	if (t1) (void)hipEventDestroy(t1);
+	if (e != hipSuccess) {
+		for (rt_context *m : g->members) { (void)hipSetDevice(m->device); (void)hipStreamSynchronize(m->stream); } // nothing may still be in flight into the slices
+		(void)hipSetDevice(root->device);
+		return group_fail(g, RT_ERR_HIP, std::string("rt_group: summing the member films: ") + hipGetErrorString(e));
+	}
 	return RT_OK;
 }
 } // namespace
@@ -972,6 +1002,8 @@ void rt_group_destroy(rt_group *g)
 		if (g->d_sum) (void)hipFree(g->d_sum);
 		if (g->d_stage) (void)hipFree(g->d_stage);
 	}
+	for (size_t i = 0; i < g->arrived.size(); i++)
+		if (g->arrived[i]) { (void)hipSetDevice(g->members[i]->device); (void)hipEventDestroy(g->arrived[i]); }
 	for (rt_context *c : g->members) rt_destroy(c);
 	delete g;
 }
@@ -1056,6 +1088,21 @@ try {
 	std::string err;
 	if (render_download_preview(root->render, samples_done, preview_img, root->stream, err, g->d_sum) != hipSuccess) return group_fail(g, RT_ERR_HIP, err);
 	return RT_OK;
+} RT_CATCH_GROUP(g)
+
+double rt_group_last_sum_ms(const rt_group *g) { return g ? g->last_sum_ms : 0.0; }
+
+// The traversal benchmark on a group: member i answers the i-th of n contiguous ranges of the rays on its own replica of the scene
+// (host buffers, like rt_trace_closest); no member needs anything from another.
+int rt_group_trace_closest(rt_group *g, const rt_ray *rays, uint64_t n, rt_hit *hits, double *t64)
+try {
+	if (!g || (n && (!rays || !hits))) return RT_ERR_INVALID;
+	const uint64_t parts = g->members.size();
+	return for_each_member(g, [&](size_t i) {
+		const uint64_t lo = n * i / parts, hi = n * (i + 1) / parts;
+		if (hi == lo) return (int)RT_OK;
+		return rt_trace_closest(g->members[i], rays + lo, hi - lo, hits + lo, t64 ? t64 + lo : nullptr);
+	});
 } RT_CATCH_GROUP(g)
 
 int rt_profile_start(rt_context *ctx)

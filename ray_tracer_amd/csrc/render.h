@@ -106,6 +106,9 @@ hipError_t render_download_film(RenderState &rs, double *out, hipStream_t stream
 hipError_t render_download_preview(RenderState &rs, int samples_done, double *out, hipStream_t stream, std::string &err, const float *film = nullptr);
 // dst += src over n film elements (both on the current device)
 hipError_t render_accumulate_film(float *dst, const float *src, size_t n, hipStream_t stream);
+// dst = src[0] + ... + src[n_src - 1] over n film elements in one pass (a group's member films; at most kMaxFilmSources)
+constexpr int kMaxFilmSources = 64;
+hipError_t render_sum_films(float *dst, const float *const *src, size_t n_src, size_t n, hipStream_t stream);
 void render_free(RenderState &rs);
 
 } // namespace mi355rt

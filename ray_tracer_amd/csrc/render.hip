@@ -2076,6 +2076,42 @@ hipError_t render_accumulate_film(float *dst, const float *src, size_t n, hipStr
 	return hipGetLastError();
 }
 
+namespace {
+struct FilmSources { const float *p[kMaxFilmSources]; };
+// dst = sum of n_src films, four elements per thread and film: one pass over every film instead of one read-modify-write of dst
+// per film (the order of the additions is the order of the films, whatever the launch)
+__global__ void __launch_bounds__(kBlock) k_film_sum(float *__restrict__ dst, FilmSources src, uint32_t n_src, uint64_t n4, uint64_t n)
+{
+	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (idx < n4) {
+		float4 acc = reinterpret_cast<const float4 *>(src.p[0])[idx];
+		for (uint32_t k = 1; k < n_src; k++) {
+			const float4 v = reinterpret_cast<const float4 *>(src.p[k])[idx];
+			acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+		}
+		reinterpret_cast<float4 *>(dst)[idx] = acc;
+	} else if (idx == n4) { // the last one to three elements
+		for (uint64_t i = 4 * n4; i < n; i++) {
+			float acc = src.p[0][i];
+			for (uint32_t k = 1; k < n_src; k++) acc += src.p[k][i];
+			dst[i] = acc;
+		}
+	}
+}
+} // namespace
+
+// dst = src[0] + src[1] + ... over n film elements (all on the current device, 16-byte aligned), on `stream`
+hipError_t render_sum_films(float *dst, const float *const *src, size_t n_src, size_t n, hipStream_t stream)
+{
+	if (n == 0 || n_src == 0) return hipSuccess;
+	if (n_src > (size_t)kMaxFilmSources) return hipErrorInvalidValue;
+	FilmSources fs{};
+	for (size_t k = 0; k < n_src; k++) fs.p[k] = src[k];
+	const uint64_t n4 = n / 4;
+	hipLaunchKernelGGL(k_film_sum, dim3((unsigned)((n4 + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, dst, fs, (uint32_t)n_src, n4, (uint64_t)n);
+	return hipGetLastError();
+}
+
 // n device floats into the caller's doubles
 static hipError_t download_widened(Impl &im, const float *src, size_t n, double *out, hipStream_t stream, std::string &err)
 {
