@@ -186,6 +186,12 @@ try {
 		delete ctx;
 		return set_err(nullptr, RT_ERR_HIP, msg);
 	}
+	if ((e = ctx->trace_work.init()) != hipSuccess) {
+		std::string msg = std::string("rt_create: work counters of the traversal kernels: ") + hipGetErrorString(e);
+		(void)hipStreamDestroy(ctx->stream);
+		delete ctx;
+		return set_err(nullptr, RT_ERR_HIP, msg);
+	}
 	*out = ctx;
 	return RT_OK;
 } RT_CATCH_CREATE
@@ -197,6 +203,7 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	render_free(ctx->render);
 	ctx->profiler.destroy();
+	ctx->trace_work.destroy();
 	ctx->free_geometry();
 	if (ctx->d_stage_rays) (void)hipFree(ctx->d_stage_rays);
 	if (ctx->d_stage_out) (void)hipFree(ctx->d_stage_out);
@@ -358,6 +365,7 @@ try {
 		}
 	}
 	lap("tree and records in place");
+	ctx->geom.work = &ctx->trace_work;
 	ctx->geom.nodes = (const float4 *)ctx->d_nodes;
 	ctx->geom.tri = (const double2 *)ctx->d_tri;
 	ctx->geom.leaf_tri = (const uint32_t *)ctx->d_leaf_tri;

@@ -10,6 +10,7 @@
 #include "mi355rt.h"
 #include "render.h"
 #include "staged_copy.h"
+#include "trace.h"
 
 struct rt_context {
 	int device = 0;
@@ -33,6 +34,7 @@ struct rt_context {
 	void *d_nodes = nullptr, *d_tri = nullptr, *d_leaf_tri = nullptr, *d_tri_face = nullptr,
 	     *d_face_object = nullptr;
 	mi355rt::DeviceGeom geom{};
+	mi355rt::TraceWork trace_work; // work counters of the traversal launches (allocated by rt_create)
 	uint64_t device_bytes = 0;
 
 	// staging for the host-buffer trace entry points (grown on demand)

@@ -17,6 +17,8 @@ namespace mi355rt {
 //             One triangle test touches exactly one line; two 48-byte records in separate arrays straddled lines 37 % of the
 //             time and cost 2.75 lines per test, the largest item after the nodes on scenes that wait for memory.
 //   leaf_tri  leaf order -> fan triangle id
+struct TraceWork; // trace.h
+
 struct DeviceGeom {
 	const float4 *nodes;
 	const double2 *tri;
@@ -29,6 +31,7 @@ struct DeviceGeom {
 	uint32_t watertight;         // 0: the reference's triangle test; 1: the watertight test (rt_set_triangle_test)
 	uint32_t surface_rays;       // 1: the rays are an integrator's (set by the render passes on their copy): they end on surfaces, so most
 	                             // node visits find a leaf and the kernel variant that always fetches a node's whole header pays
+	TraceWork *work;             // host side only (kernels ignore it): the context's work counters for the traversal launches, or null
 };
 
 } // namespace mi355rt

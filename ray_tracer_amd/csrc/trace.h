@@ -14,6 +14,23 @@ hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint6
 hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, uint8_t *d_out, hipStream_t stream,
                             const uint32_t *d_n = nullptr);
 
+// Work counters of the traversal launches.  The waves of a launch are persistent; which 64-ray chunks a wave traces is not fixed at
+// launch (fixed shares leave the chip half empty while the slowest waves finish theirs: rays differ in cost by an order of magnitude)
+// but taken chunk by chunk from counters in device memory: kWorkGroups counters per XCD, each shared by the workgroups of one group,
+// so that no counter sees more than one atomic per few hundred nanoseconds.  Every launch zeroes and uses one of kWorkSets sets;
+// launches of one context on different streams may overlap, so a set is reused only behind the launch that used it last (an event,
+// waited for on the device).  One per context, allocated by init() with the context's device current; no call after that allocates.
+constexpr int kWorkSets = 32, kWorkGroups = 16, kWorkStride = 16; // counters are kWorkStride uint32 (64 bytes) apart
+struct TraceWork {
+	uint32_t *d_counters = nullptr; // kWorkSets x 8 XCDs x kWorkGroups counters
+	hipEvent_t done[kWorkSets] = {};
+	bool used[kWorkSets] = {};
+	int next = 0;
+	hipError_t init();
+	void destroy();
+	static constexpr size_t set_words() { return (size_t)8 * kWorkGroups * kWorkStride; }
+};
+
 // Staging memory that exists without any allocation: a file-scope device array of the traversal code object, one copy per GPU,
 // sized for kStaticRays rays with their hits and fp64 distances.  static_stage() returns the address of the calling device's copy
 // (looked up once per device, with that device current) and must be called with `device` current.

@@ -29,7 +29,14 @@ namespace {
 // how many node steps a ray needs: a ray of the Cornell box needs 1.7, rays end in bulk, and late refills / early exits win (16 / 62);
 // a ray inside a 490 k-triangle hall needs 13, and 8 / 56 is 24 % faster there (and 2.6 % slower on the box); a soup that waits for
 // memory wants 8 / 48 (62 costs it 18 %).
-struct TraceTuning { uint32_t refill_min, node_min_lanes; };
+// A third one says how the 64-ray chunks of a launch are dealt to the eight XCDs (each has an L2 of its own): one contiguous eighth
+// each (kXcdContiguous: a caller that has ordered its rays in space, and the library's own ordering by origin cell, keep one part of
+// the scene per L2), or blocks of 2^xcd_block_log chunks in turn.  An integrator's rays come in pixel order, and an eighth of the
+// image can cost twice what another costs (sky against a colonnade): with the waves' shares fixed at launch, the kernel then lasts
+// as long as its most expensive eighth.  Dealt out in blocks of 32 chunks the eighths cost the same and neighbouring pixels still
+// share an L2 (the hall's render rays: +6 % when shuffled at random, which gives up the neighbourhood as well).
+struct TraceTuning { uint32_t refill_min, node_min_lanes, xcd_block_log; };
+constexpr uint32_t kXcdContiguous = 0xFFu;
 #ifndef TRACE_COOP_LEAF
 #define TRACE_COOP_LEAF 1
 #endif
@@ -206,7 +213,7 @@ __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return (floa
 template <bool LDS_STACK, bool ANY, bool WT, bool RESIDENT>
 __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGeom g, TraceTuning tune, const rt_ray *__restrict__ rays, uint64_t n_bound,
                                                   rt_hit *__restrict__ hits, double *__restrict__ t64,
-                                                  uint8_t *__restrict__ any_out, const uint32_t *__restrict__ n_dev)
+                                                  uint8_t *__restrict__ any_out, const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ work)
 {
 	const uint64_t n = n_dev ? (uint64_t)*n_dev : n_bound;
 #ifdef TRACE_STATS
@@ -215,6 +222,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 #define TRACE_COUNT(iter, lanes) do { if (lane == __ffsll((long long)__ballot(true)) - 1) iter++; lanes++; } while (0)
 	// shader-clock time per section of the main loop, accumulated by lane 0 of every wave (sections end where the next begins)
 	long long st_clk[6] = {0, 0, 0, 0, 0, 0}, st_t0 = clock64();
+	const unsigned long long st_wall0 = wall_clock64();
 #define TRACE_LAP(k) do { const long long now_ = clock64(); st_clk[k] += now_ - st_t0; st_t0 = now_; } while (0)
 #else
 #define TRACE_COUNT(iter, lanes) do { } while (0)
@@ -230,17 +238,33 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 	const int lane = threadIdx.x & 63;
 	const unsigned long long lt = (1ull << lane) - 1ull;
 	// Workgroups go to the eight XCDs round robin (workgroup b runs on XCD b mod 8), and every XCD has an L2 of
-	// its own.  Each XCD therefore takes one contiguous eighth of the 64-ray chunks, and its waves walk through
-	// that eighth together (wave w of the XCD owns chunks w, w + W, ...): when the caller has ordered the rays
-	// spatially, the waves that share an L2 work in the same part of the tree at the same time.
+	// its own.  Each XCD therefore takes one share of the 64-ray chunks -- a contiguous eighth, or blocks dealt in turn (TraceTuning)
+	// -- and its waves walk through that share together: when the caller has ordered the rays spatially, the waves that share an L2
+	// work in the same part of the tree at the same time.  Inside the share a wave takes its chunks one at a time: from the work
+	// counter of its group of workgroups (`work` set: chunk k * groups + group for the k the counter hands out), or, without
+	// counters, the fixed sequence wave, wave + W, ...
 	const bool by_xcd = (gridDim.x & 7u) == 0;
 	const uint64_t n_chunks = (n + 63) >> 6;
-	const uint64_t n_waves = by_xcd ? (uint64_t)(gridDim.x >> 3) * (kBlock / 64) : (uint64_t)gridDim.x * (kBlock / 64);
-	const uint64_t wave_id = by_xcd ? (uint64_t)(blockIdx.x >> 3) * (kBlock / 64) + (threadIdx.x >> 6)
-	                                : (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const uint64_t chunk_lo = by_xcd ? n_chunks * (blockIdx.x & 7u) / 8 : 0;
-	const uint64_t chunk_hi = by_xcd ? n_chunks * ((blockIdx.x & 7u) + 1) / 8 : n_chunks;
-	uint64_t next = 0; // position in this wave's own sequence of rays
+	const uint32_t wgs = by_xcd ? gridDim.x >> 3 : gridDim.x, wg = by_xcd ? blockIdx.x >> 3 : blockIdx.x; // workgroups of this share, and which one this is
+	const uint64_t n_waves = (uint64_t)wgs * (kBlock / 64);
+	const uint64_t wave_id = (uint64_t)wg * (kBlock / 64) + (threadIdx.x >> 6);
+	const bool dealt = by_xcd && tune.xcd_block_log != kXcdContiguous;
+	const uint64_t chunk_lo = by_xcd && !dealt ? n_chunks * (blockIdx.x & 7u) / 8 : 0;
+	const uint64_t chunk_hi = by_xcd && !dealt ? n_chunks * ((blockIdx.x & 7u) + 1) / 8 : n_chunks;
+	// the v-th chunk of this XCD's share, v = 0, 1, ...; a value >= chunk_hi says there is none (and none for any larger v)
+	const uint32_t xlog = dealt ? tune.xcd_block_log : 0u;
+	const uint64_t xcd = by_xcd ? (blockIdx.x & 7u) : 0u;
+	auto chunk_of = [&](uint64_t v) -> uint64_t {
+		return dealt ? ((((v >> xlog) << 3) + xcd) << xlog) + (v & ((1ull << xlog) - 1ull)) : chunk_lo + v;
+	};
+	const uint32_t n_groups = wgs < (uint32_t)kWorkGroups ? wgs : (uint32_t)kWorkGroups, group = wg % n_groups;
+	uint32_t *const counter = work ? work + ((size_t)xcd * kWorkGroups + group) * kWorkStride : nullptr;
+	uint64_t taken = 0;        // chunks this wave has taken so far (without counters: its position in the fixed sequence)
+	uint64_t cur_chunk = 0;    // the chunk the wave is handing out
+	uint32_t cur_pos = 64;     // rays of it already handed out (64: none left)
+	bool out_of_work = false;
+	uint32_t k_ahead = 0;      // lane 0: the counter's answer for the chunk after the current one
+	if (counter && lane == 0) k_ahead = atomicAdd(counter, 1u);
 
 	bool active = false;
 	uint64_t ray_id = 0;
@@ -255,15 +279,34 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 	uint32_t l1_base = 0, l1_m0 = 0, l1_m1 = 0, l1_hits = 0; // parked leaf group 1
 
 	for (;;) {
-		// ---- hand new rays to idle lanes
-		const unsigned long long idle = __ballot(!active);
-		if (idle != 0 && chunk_lo + (next >> 6) * n_waves + wave_id < chunk_hi) {
-			const int nidle = __popcll(idle);
-			if (nidle >= (int)tune.refill_min) {
-				const uint64_t seq = next + (uint64_t)__popcll(idle & lt);
-				const uint64_t chunk = chunk_lo + (seq >> 6) * n_waves + wave_id;
-				const uint64_t mine = chunk * 64 + (seq & 63);
-				if (!active && chunk < chunk_hi && mine < n) {
+		// ---- hand new rays to idle lanes: what is left of the wave's current chunk, then the start of its next one.  The chunk after
+		// that is asked for at the same time (the counter's answer travels with the ray loads and is not needed before the next
+		// change of chunk), so a change of chunk costs no round trip of its own.
+		{
+			const unsigned long long idle = __ballot(!active);
+			if (idle != 0 && !out_of_work && __popcll(idle) >= (int)tune.refill_min) {
+				const uint32_t nidle = (uint32_t)__popcll(idle), rank = (uint32_t)__popcll(idle & lt);
+				const uint32_t rem = 64u - cur_pos; // rays left in the current chunk
+				uint64_t chunk_b = ~0ull;
+				if (nidle > rem) {
+					uint64_t v;
+					if (counter) {
+						const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_ahead);
+						v = (uint64_t)k * n_groups + group;
+						if (lane == 0) k_ahead = atomicAdd(counter, 1u);
+					} else {
+						v = taken * n_waves + wave_id;
+					}
+					taken++;
+					chunk_b = chunk_of(v);
+					if (chunk_b >= chunk_hi) { out_of_work = true; chunk_b = ~0ull; }
+				}
+				uint64_t mine = ~0ull;
+				if (rank < rem) mine = cur_chunk * 64 + cur_pos + rank;
+				else if (chunk_b != ~0ull) mine = chunk_b * 64 + (rank - rem);
+				if (nidle > rem) { cur_chunk = chunk_b; cur_pos = chunk_b != ~0ull ? nidle - rem : 64u; }
+				else cur_pos += nidle;
+				if (!active && mine < n) {
 					const float4 ra = reinterpret_cast<const float4 *>(rays)[2 * mine];
 					const float4 rb = reinterpret_cast<const float4 *>(rays)[2 * mine + 1];
 					ray_id = mine;
@@ -304,11 +347,13 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					l1_hits = 0;
 					active = true;
 				}
-				next += (uint64_t)nidle;
 			}
 		}
 		TRACE_LAP(0); // refill
-		if (__ballot(active) == 0) break;
+		if (__ballot(active) == 0) {
+			if (out_of_work) break;
+			continue; // the chunk ended short of the batch's last ray, or on a lane boundary: take the next one
+		}
 		if (active) {
 			TRACE_COUNT(st_outer, st_outer_lanes);
 			// ---- node phase
@@ -584,6 +629,12 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 		atomicAdd(&sink[4], st_outer); atomicAdd(&sink[5], st_outer_lanes);
 		atomicAdd(&sink[6], st_in_iter); atomicAdd(&sink[7], st_in_lanes);
 		if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&sink[8 + k], (unsigned long long)st_clk[k]);
+		// when the waves ended, on the chip-wide 100 MHz counter: first and last start, sum and last of the ends, number of waves
+		if (lane == 0) {
+			const unsigned long long t_end = wall_clock64();
+			atomicMin(&sink[14], st_wall0); atomicMax(&sink[15], st_wall0);
+			atomicAdd(&sink[16], t_end); atomicMax(&sink[17], t_end); atomicAdd(&sink[18], 1ull);
+		}
 	}
 #endif
 }
@@ -621,17 +672,38 @@ hipError_t launch_trace(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, r
 	bool resident = g.tri_stride == 7 || g.surface_rays != 0;
 	static const char *const force = std::getenv("MI355RT_TRACE_RESIDENT"); // experiments: 0 / 1 overrides the choice
 	if (force && (force[0] == '0' || force[0] == '1')) resident = force[0] == '1';
-	TraceTuning tune = g.tri_stride == 7 ? TraceTuning{16u, 62u} : (g.surface_rays ? TraceTuning{8u, 56u} : TraceTuning{8u, 48u});
-	static const char *const t_refill = std::getenv("MI355RT_TRACE_REFILL"), *const t_lanes = std::getenv("MI355RT_TRACE_NODE_LANES"); // experiments
+	TraceTuning tune = g.tri_stride == 7 ? TraceTuning{16u, 62u, kXcdContiguous} : (g.surface_rays ? TraceTuning{8u, 56u, kXcdContiguous} : TraceTuning{8u, 48u, kXcdContiguous});
+	if (g.surface_rays) tune.xcd_block_log = 5; // an integrator's rays, in pixel order: blocks of 32 chunks to the XCDs in turn
+	static const char *const t_refill = std::getenv("MI355RT_TRACE_REFILL"), *const t_lanes = std::getenv("MI355RT_TRACE_NODE_LANES"), // experiments
+	                  *const t_xcd = std::getenv("MI355RT_TRACE_XCD_BLOCK");
 	if (t_refill) tune.refill_min = (uint32_t)std::max(1, std::min(64, std::atoi(t_refill)));
 	if (t_lanes) tune.node_min_lanes = (uint32_t)std::max(0, std::min(64, std::atoi(t_lanes)));
-#define TRACE_LAUNCH(L, W, R) hipLaunchKernelGGL((k_trace<L, ANY, W, R>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, tune, d_rays, n, d_hits, d_t64, d_any, d_n)
+	if (t_xcd) tune.xcd_block_log = std::atoi(t_xcd) < 0 ? kXcdContiguous : (uint32_t)std::min(20, std::atoi(t_xcd));
+	// the launch's set of work counters: zeroed on the stream, behind whichever launch used the set last
+	uint32_t *d_work = nullptr;
+	int set = -1;
+	static const char *const t_dyn = std::getenv("MI355RT_TRACE_DYNAMIC"); // experiments: 0 = fixed shares per wave
+	if (g.work && g.work->d_counters && !(t_dyn && t_dyn[0] == '0')) {
+		TraceWork &w = *g.work;
+		set = w.next;
+		w.next = (w.next + 1) % kWorkSets;
+		hipError_t e = w.used[set] ? hipStreamWaitEvent(stream, w.done[set], 0) : hipSuccess;
+		d_work = w.d_counters + (size_t)set * TraceWork::set_words();
+		if (e == hipSuccess) e = hipMemsetAsync(d_work, 0, TraceWork::set_words() * sizeof(uint32_t), stream);
+		if (e != hipSuccess) return e;
+	}
+#define TRACE_LAUNCH(L, W, R) hipLaunchKernelGGL((k_trace<L, ANY, W, R>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, tune, d_rays, n, d_hits, d_t64, d_any, d_n, d_work)
 #define TRACE_LAUNCH_R(L, W) do { if (resident) TRACE_LAUNCH(L, W, true); else TRACE_LAUNCH(L, W, false); } while (0)
 	if (g.watertight) { if (lds) TRACE_LAUNCH_R(true, true); else TRACE_LAUNCH_R(false, true); }
 	else { if (lds) TRACE_LAUNCH_R(true, false); else TRACE_LAUNCH_R(false, false); }
 #undef TRACE_LAUNCH_R
 #undef TRACE_LAUNCH
-	return hipGetLastError();
+	hipError_t e = hipGetLastError();
+	if (set >= 0 && e == hipSuccess) {
+		e = hipEventRecord(g.work->done[set], stream);
+		g.work->used[set] = e == hipSuccess;
+	}
+	return e;
 }
 } // namespace
 
@@ -654,6 +726,27 @@ constexpr int kMaxDevices = 64;
 unsigned char *g_scratch_ptr[kMaxDevices]; // per device: every GPU holds its own copy of the array at its own address
 std::mutex g_scratch_mutex;
 } // namespace
+
+hipError_t TraceWork::init()
+{
+	destroy();
+	hipError_t e = hipMalloc((void **)&d_counters, (size_t)kWorkSets * set_words() * sizeof(uint32_t));
+	for (int i = 0; i < kWorkSets && e == hipSuccess; i++) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+	if (e != hipSuccess) destroy();
+	return e;
+}
+
+void TraceWork::destroy()
+{
+	for (int i = 0; i < kWorkSets; i++) {
+		if (done[i]) (void)hipEventDestroy(done[i]);
+		done[i] = nullptr;
+		used[i] = false;
+	}
+	if (d_counters) (void)hipFree(d_counters);
+	d_counters = nullptr;
+	next = 0;
+}
 
 hipError_t static_stage(int device, StaticStage &out)
 {

@@ -45,6 +45,8 @@ else:
 d_rays = torch.from_numpy(rays).cuda()
 d_hits = torch.empty((m, 4), dtype=torch.int32, device='cuda')
 sink = torch.zeros(m, dtype=torch.float64, device='cuda')
+sink[:20].view(torch.int64)[14] = (1 << 62)  # minimum of the waves' start times
+torch.cuda.synchronize()
 ctx.trace_closest_device(d_rays.data_ptr(), m, d_hits.data_ptr(), sink.data_ptr()); ctx.render_sync()
 s = sink[:16].view(torch.int64).cpu().numpy()
 print("rays %d" % m)
@@ -56,3 +58,10 @@ clk = s[8:14].astype(float)
 if clk.sum() > 0:
     names = ["refill", "node phase", "count+publish", "fetch+test", "merge+readback", "write results"]
     print("wave time by section: " + ", ".join("%s %.1f%%" % (n, 100 * c / clk.sum()) for n, c in zip(names, clk)))
+w = sink[:20].view(torch.int64).cpu().numpy()
+if w[18] > 0:
+    first, last_start, sum_end, last_end, n_w = int(w[14]), int(w[15]), int(w[16]), int(w[17]), int(w[18])
+    span = last_end - first
+    print("waves %d: kernel spans %.1f us; the mean wave ends %.1f %% before the last one (static shares: that time is idle)" %
+          (n_w, span / 100.0, 100.0 * (1.0 - (sum_end / n_w - first) / max(span, 1))))
+
