@@ -20,7 +20,10 @@ hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t 
 // so that no counter sees more than one atomic per few hundred nanoseconds.  Every launch zeroes and uses one of kWorkSets sets;
 // launches of one context on different streams may overlap, so a set is reused only behind the launch that used it last (an event,
 // waited for on the device).  One per context, allocated by init() with the context's device current; no call after that allocates.
-constexpr int kWorkSets = 32, kWorkGroups = 16, kWorkStride = 16; // counters are kWorkStride uint32 (64 bytes) apart
+#ifndef TRACE_WORK_GROUPS
+#define TRACE_WORK_GROUPS 16
+#endif
+constexpr int kWorkSets = 32, kWorkGroups = TRACE_WORK_GROUPS, kWorkStride = 16; // counters are kWorkStride uint32 (64 bytes) apart
 struct TraceWork {
 	uint32_t *d_counters = nullptr; // kWorkSets x 8 XCDs x kWorkGroups counters
 	hipEvent_t done[kWorkSets] = {};

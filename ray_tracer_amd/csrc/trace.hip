@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 	const uint64_t n = n_dev ? (uint64_t)*n_dev : n_bound;
 #ifdef TRACE_STATS
 	// diagnostic build only: per-lane trip counts of the three loops (summed into the t64 buffer at the end)
+	unsigned st_ray_steps = 0, st_ray_outer = 0; // node steps and passes of the main loop of the lane's current ray
 	unsigned long long st_node_iter = 0, st_node_lanes = 0, st_leaf_iter = 0, st_leaf_lanes = 0, st_outer = 0, st_outer_lanes = 0, st_in_iter = 0, st_in_lanes = 0;
 #define TRACE_COUNT(iter, lanes) do { if (lane == __ffsll((long long)__ballot(true)) - 1) iter++; lanes++; } while (0)
 	// shader-clock time per section of the main loop, accumulated by lane 0 of every wave (sections end where the next begins)
@@ -227,6 +228,9 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 #else
 #define TRACE_COUNT(iter, lanes) do { } while (0)
 #define TRACE_LAP(k) do { } while (0)
+#endif
+#ifdef TRACE_ENDTIMES
+	const unsigned long long et_wall0 = wall_clock64();
 #endif
 #if TRACE_COOP_LEAF
 	__shared__ uint32_t coop_owner[kBlock / 64][64];
@@ -367,6 +371,9 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				if (l1_hits != 0) break; // two parked leaf groups: wait for the triangle phase
 				// nearest pending child of the group
 				TRACE_COUNT(st_node_iter, st_node_lanes);
+#ifdef TRACE_STATS
+				st_ray_steps++;
+#endif
 				const uint32_t pos = (uint32_t)__ffs((int)(g_mask & 0xFFu)) - 1u;
 				g_mask &= ~(1u << pos);
 				const uint32_t slot = pos ^ (oct & 7u);
@@ -593,7 +600,19 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 #endif
 			// ---- finished: write the result, free the lane
 			const bool out_of_nodes = (g_mask & 0xFFu) == 0 && sp == 0;
+#ifdef TRACE_STATS
+			st_ray_outer++;
+#endif
 			if ((ANY && found_any) || (out_of_nodes && l0_hits == 0 && l1_hits == 0)) {
+#ifdef TRACE_STATS
+				if (t64 && n > 1000000) { // histograms over the rays: node steps (powers of two) and passes of the main loop the ray was resident for
+					unsigned long long *sink = reinterpret_cast<unsigned long long *>(t64);
+					atomicAdd(&sink[32 + (st_ray_steps ? 32 - __clz(st_ray_steps) : 0)], 1ull);
+					atomicAdd(&sink[72 + (st_ray_outer ? 32 - __clz(st_ray_outer) : 0)], 1ull);
+				}
+				st_ray_steps = 0;
+				st_ray_outer = 0;
+#endif
 				if (ANY) {
 					any_out[ray_id] = found_any ? 1 : 0;
 				} else {
@@ -610,7 +629,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 						h.object = RT_MISS;
 					}
 					reinterpret_cast<uint4 *>(hits)[ray_id] = *reinterpret_cast<uint4 *>(&h);
-#ifndef TRACE_STATS
+#if !defined(TRACE_STATS) && !defined(TRACE_ENDTIMES)
 					if (t64) t64[ray_id] = best != RT_MISS ? t_best : (double)__int_as_float(0x7f800000);
 #endif
 				}
@@ -621,7 +640,17 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 		}
 		TRACE_LAP(5); // writing results
 	}
+#ifdef TRACE_ENDTIMES
+	// diagnostic build: when the waves ended, and nothing else (the full statistics slow the kernel down threefold)
+	if (t64 && n > 1000000 && lane == 0) {
+		const unsigned long long t_end = wall_clock64();
+		unsigned long long *sink = reinterpret_cast<unsigned long long *>(t64);
+		atomicMin(&sink[14], et_wall0); atomicMax(&sink[15], et_wall0);
+		atomicAdd(&sink[16], t_end); atomicMax(&sink[17], t_end); atomicAdd(&sink[18], 1ull);
+	}
+#endif
 #ifdef TRACE_STATS
+	const unsigned long long st_wall1 = wall_clock64(); // before the counters below are added up: those atomics are not the kernel's
 	if (t64 && n > 1000000) {
 		unsigned long long *sink = reinterpret_cast<unsigned long long *>(t64);
 		atomicAdd(&sink[0], st_node_iter); atomicAdd(&sink[1], st_node_lanes);
@@ -631,7 +660,7 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 		if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&sink[8 + k], (unsigned long long)st_clk[k]);
 		// when the waves ended, on the chip-wide 100 MHz counter: first and last start, sum and last of the ends, number of waves
 		if (lane == 0) {
-			const unsigned long long t_end = wall_clock64();
+			const unsigned long long t_end = st_wall1;
 			atomicMin(&sink[14], st_wall0); atomicMax(&sink[15], st_wall0);
 			atomicAdd(&sink[16], t_end); atomicMax(&sink[17], t_end); atomicAdd(&sink[18], 1ull);
 		}

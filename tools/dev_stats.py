@@ -62,6 +62,9 @@ w = sink[:20].view(torch.int64).cpu().numpy()
 if w[18] > 0:
     first, last_start, sum_end, last_end, n_w = int(w[14]), int(w[15]), int(w[16]), int(w[17]), int(w[18])
     span = last_end - first
-    print("waves %d: kernel spans %.1f us; the mean wave ends %.1f %% before the last one (static shares: that time is idle)" %
-          (n_w, span / 100.0, 100.0 * (1.0 - (sum_end / n_w - first) / max(span, 1))))
+    print("waves %d: from the first wave's start to the last wave's end %.1f us; the last wave starts %.1f us in; the mean wave ends %.1f %% of that span before the last one (idle time)" %
+          (n_w, span / 100.0, (last_start - first) / 100.0, 100.0 * (1.0 - (sum_end / n_w - first) / max(span, 1))))
+h = sink[:128].view(torch.int64).cpu().numpy()
+print("rays by node steps (bucket = highest power of two not above the count; first bucket: none): " + " ".join("%d:%d" % (1 << (k - 1) if k else 0, h[32 + k]) for k in range(0, 24) if h[32 + k]))
+print("rays by passes of the wave's main loop they were resident for: " + " ".join("%d:%d" % (1 << (k - 1) if k else 0, h[72 + k]) for k in range(0, 24) if h[72 + k]))
 
