@@ -441,7 +441,9 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 					else { l1_base = h1.y; l1_m0 = h1.z; l1_m1 = h1.w; l1_hits = leaf_hits; }
 				}
 				if (__ballot(l0_hits == 0) == 0) break; // every lane still descending already holds triangles to test
-				if (__popcll(__ballot(true)) < (int)tune.node_min_lanes) break; // too few lanes left descending
+				// too few lanes left descending.  Once the wave has no more rays to take, leaving early buys nothing (no lane that is freed
+				// will be used again) and costs a pass through the rest of the main loop per node step of the last, long rays.
+				if (__popcll(__ballot(true)) < (int)(out_of_work ? 1u : tune.node_min_lanes)) break;
 			}
 #if TRACE_COOP_LEAF
 		}
