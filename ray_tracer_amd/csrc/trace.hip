@@ -27,8 +27,9 @@ namespace {
 // Two thresholds steer a wave, both launch arguments (they sit in scalar registers): the number of idle lanes at which it takes new
 // rays, and the number of descending lanes below which it leaves the node phase for the triangle phase.  What is best depends on
 // how many node steps a ray needs: a ray of the Cornell box needs 1.7, rays end in bulk, and late refills / early exits win (16 / 62);
-// a ray inside a 490 k-triangle hall needs 13, and 8 / 56 is 24 % faster there (and 2.6 % slower on the box); a soup that waits for
-// memory wants 8 / 48 (62 costs it 18 %).
+// a ray inside a 490 k-triangle hall needs 13, and 8 / 40 is 30 % faster there (and slower on the box; 8 / 56 was the best before the
+// waves took their rays from work counters: 6.11 against 6.41 Grays/s now); a soup that waits for memory wants 8 / 48 (62 costs it
+// 25 %).
 // A third one says how the 64-ray chunks of a launch are dealt to the eight XCDs (each has an L2 of its own): one contiguous eighth
 // each (kXcdContiguous: a caller that has ordered its rays in space, and the library's own ordering by origin cell, keep one part of
 // the scene per L2), or blocks of 2^xcd_block_log chunks in turn.  An integrator's rays come in pixel order, and an eighth of the
@@ -703,7 +704,7 @@ hipError_t launch_trace(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, r
 	bool resident = g.tri_stride == 7 || g.surface_rays != 0;
 	static const char *const force = std::getenv("MI355RT_TRACE_RESIDENT"); // experiments: 0 / 1 overrides the choice
 	if (force && (force[0] == '0' || force[0] == '1')) resident = force[0] == '1';
-	TraceTuning tune = g.tri_stride == 7 ? TraceTuning{16u, 62u, kXcdContiguous} : (g.surface_rays ? TraceTuning{8u, 56u, kXcdContiguous} : TraceTuning{8u, 48u, kXcdContiguous});
+	TraceTuning tune = g.tri_stride == 7 ? TraceTuning{16u, 62u, kXcdContiguous} : (g.surface_rays ? TraceTuning{8u, 40u, kXcdContiguous} : TraceTuning{8u, 48u, kXcdContiguous});
 	if (g.surface_rays) tune.xcd_block_log = 5; // an integrator's rays, in pixel order: blocks of 32 chunks to the XCDs in turn
 	static const char *const t_refill = std::getenv("MI355RT_TRACE_REFILL"), *const t_lanes = std::getenv("MI355RT_TRACE_NODE_LANES"), // experiments
 	                  *const t_xcd = std::getenv("MI355RT_TRACE_XCD_BLOCK");
