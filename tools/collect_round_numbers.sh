@@ -5,7 +5,7 @@ timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err
 for a in naive nee mis bdpt; do timeout -k 10 200 python bench.py --no-cpu --no-soup --algorithm $a --steps 6 --warmup 1 > $O/alg_$a.json 2>> $O/alg.err; done
 timeout -k 10 300 python tools/bench_ply_scene.py --material glass > $O/ply_glass.json 2> $O/ply.err
 timeout -k 10 300 python tools/bench_ply_scene.py --material gold > $O/ply_gold.json 2>> $O/ply.err
-BENCH_REHEARSAL=1 timeout -k 10 300 python bench.py --gpus 2 --steps 4 --warmup 1 --no-cpu --no-soup > $O/rehearsal.out 2> $O/rehearsal.err
+BENCH_REHEARSAL=1 timeout -k 10 400 python bench.py --gpus 2 --steps 4 --warmup 1 --no-cpu > $O/rehearsal.out 2> $O/rehearsal.err
 
 timeout -k 10 300 python tools/bench_hall.py > gpurun_out/final/hall.json 2> gpurun_out/final/hall.err
 echo collected
