@@ -1734,8 +1734,16 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 		first_round = false;
 		uint64_t bound = entering;
 		int known = 0, b = 0;
-		long rec_path[kMaxBounces + 1], rec_conn[kMaxBounces + 1];
-		bool empty = false, cut = false;
+		// profiler records of bounce k: its path trace (-1 when the launch over the previous bounce's connection rays took the path
+		// rays along), shade, connection trace, connect
+		long rec_tp[kMaxBounces + 1], rec_sh[kMaxBounces + 1], rec_tc[kMaxBounces + 1], rec_co[kMaxBounces + 1];
+		bool took_next[kMaxBounces + 1]; // the connection trace of bounce k also traced the path rays of bounce k + 1
+		bool empty = false, cut = false, pre_traced = false;
+		// MIS traces its connection rays for the closest hit, like its path rays, and both queues are filled by the same shade launch:
+		// the connection rays of bounce b and the path rays of bounce b + 1 go into one launch (every launch ends with a few long rays
+		// running alone; one launch has one such tail where two have two)
+		static const char *const two_env = std::getenv("MI355RT_TRACE_TWO"); // experiments: 0 = one launch per queue
+		const bool two = ALG == RT_ALG_MIS && !rs.capture_buf && !(two_env && two_env[0] == '0');
 		for (; b < kMaxBounces; b++) {
 			while (known < b) { // take the counts that have arrived; never run more than two bounces ahead
 				if (b - known > 2 || rs.capture_buf) HIP_TRY(hipEventSynchronize(im.ev[known + 1]));
@@ -1744,14 +1752,20 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 				bound = std::min<uint64_t>(bound, (uint32_t)im.h_counters[known].tails);
 			}
 			if (bound == 0) { empty = true; break; }
-			if (b >= 1 && bound <= carry_limit) { cut = true; break; } // few paths left: they join the next batch
+			// few paths left: they join the next batch (unless they have been traced already: then they are shaded first)
+			if (!pre_traced && b >= 1 && bound <= carry_limit) { cut = true; break; }
 			const uint32_t *n_path = reinterpret_cast<const uint32_t *>(&im.counters[b]);
 			const uint32_t *n_conn = reinterpret_cast<const uint32_t *>(&im.counters[b + 1]) + 1;
-			if (rs.capture_buf) HIP_TRY(capture(im.rays[cur], bound)); // capture mode is synchronous: bound is exact here
-			prof.begin(Profiler::CLOSEST, bound, stream);
-			HIP_TRY(launch_trace_closest(geom, im.rays[cur], bound, im.hits, nullptr, stream, n_path));
-			prof.end(stream);
-			rec_path[b] = prof.last();
+			rec_tp[b] = rec_tc[b] = rec_co[b] = -1;
+			took_next[b] = false;
+			if (!pre_traced) {
+				if (rs.capture_buf) HIP_TRY(capture(im.rays[cur], bound)); // capture mode is synchronous: bound is exact here
+				prof.begin(Profiler::CLOSEST, bound, stream);
+				HIP_TRY(launch_trace_closest(geom, im.rays[cur], bound, im.hits, nullptr, stream, n_path));
+				prof.end(stream);
+				rec_tp[b] = prof.last();
+			}
+			pre_traced = false;
 			prof.begin(Profiler::SHADE, bound, stream);
 			{
 				const dim3 grid((unsigned)((bound + kShadeBlock - 1) / kShadeBlock));
@@ -1763,10 +1777,10 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 					                   im.rays[cur ^ 1], im.state[cur ^ 1], im.conn_rays, reinterpret_cast<ConnRecU *>(im.conn), &im.counters[b + 1], rs.d_film);
 			}
 			prof.end(stream);
+			rec_sh[b] = prof.last();
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipMemcpyAsync(&im.h_counters[b + 1], &im.counters[b + 1], sizeof(Counters), hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipEventRecord(im.ev[b + 1], stream));
-			rec_conn[b] = -1;
 			if (ALG != RT_ALG_NAIVE) {
 				uint64_t conn_bound = 2 * bound;
 				if (rs.capture_buf) {
@@ -1779,12 +1793,21 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 						prof.begin(Profiler::ANY, conn_bound, stream);
 						HIP_TRY(launch_trace_any(geom, im.conn_rays, conn_bound, im.conn_any, stream, n_conn));
 						prof.end(stream);
+					} else if (two && b + 1 < kMaxBounces && bound > carry_limit) {
+						// the next bounce will run (as far as the counts known now say; if it turns out to be small it runs all the same):
+						// its path rays, which the shade launch above has just written, are traced together with these connection rays
+						const uint32_t *n_next = reinterpret_cast<const uint32_t *>(&im.counters[b + 1]);
+						prof.begin(Profiler::CLOSEST, conn_bound + bound, stream);
+						HIP_TRY(launch_trace_closest_two(geom, im.conn_rays, conn_bound, im.conn_hits, n_conn, im.rays[cur ^ 1], bound, im.hits, n_next, stream));
+						prof.end(stream);
+						took_next[b] = true;
+						pre_traced = true;
 					} else {
 						prof.begin(Profiler::CLOSEST, conn_bound, stream);
 						HIP_TRY(launch_trace_closest(geom, im.conn_rays, conn_bound, im.conn_hits, nullptr, stream, n_conn));
 						prof.end(stream);
 					}
-					rec_conn[b] = prof.last();
+					rec_tc[b] = prof.last();
 					prof.begin(Profiler::CONNECT, conn_bound, stream);
 					if (im.g_code)
 						hipLaunchKernelGGL((k_connect<ALG, true>), dim3(stream_grid(conn_bound, kBlock)), dim3(kBlock), 0, stream, geom, sh,
@@ -1794,7 +1817,7 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 						                   n_conn, im.conn_rays, reinterpret_cast<const ConnRecU *>(im.conn), im.conn_hits, im.conn_any, rs.d_film);
 					prof.end(stream);
 					HIP_TRY(hipGetLastError());
-					if (rec_conn[b] >= 0) rec_conn[b] = prof.last() - 1;
+					rec_co[b] = prof.last();
 				}
 			}
 			cur ^= 1;
@@ -1806,9 +1829,10 @@ static hipError_t run_batch(RenderState &rs, Impl &im, const DeviceGeom &geom, i
 			rs.closest_rays += np;
 			if (ALG == RT_ALG_NEE) rs.any_rays += nc;
 			else if (ALG == RT_ALG_MIS) rs.closest_rays += nc;
-			prof.set_items(rec_path[k], np);
-			prof.set_items(rec_path[k] >= 0 ? rec_path[k] + 1 : -1, np);
-			if (rec_conn[k] >= 0) { prof.set_items(rec_conn[k], nc); prof.set_items(rec_conn[k] + 1, nc); }
+			prof.set_items(rec_tp[k], np);
+			prof.set_items(rec_sh[k], np);
+			prof.set_items(rec_tc[k], nc + (took_next[k] ? (uint64_t)(uint32_t)im.h_counters[k + 1].tails : 0));
+			prof.set_items(rec_co[k], nc);
 		}
 		if (empty) break;
 		entering = (uint32_t)im.h_counters[b].tails; // exact now; the survivors sit at the front of rays[cur]

@@ -10,6 +10,10 @@ constexpr uint32_t kTraceMaxDepth = 96;
 // from it (a count produced by an earlier kernel on the same stream) and n is only an upper bound that sizes the grid.
 hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, hipStream_t stream,
                                 const uint32_t *d_n = nullptr);
+// closest hit over two batches of rays in one launch, each with its own results and its own count (an upper bound on the host, the
+// exact count in device memory when d_n_* is not null): one launch has one tail where two have two
+hipError_t launch_trace_closest_two(const DeviceGeom &g, const rt_ray *d_rays_a, uint64_t n_a, rt_hit *d_hits_a, const uint32_t *d_n_a,
+                                    const rt_ray *d_rays_b, uint64_t n_b, rt_hit *d_hits_b, const uint32_t *d_n_b, hipStream_t stream);
 // any hit: d_out[i] = 1 when some triangle is hit inside [tmin, tmax]
 hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, uint8_t *d_out, hipStream_t stream,
                             const uint32_t *d_n = nullptr);

@@ -38,6 +38,8 @@ namespace {
 // share an L2 (the hall's render rays: +6 % when shuffled at random, which gives up the neighbourhood as well).
 struct TraceTuning { uint32_t refill_min, node_min_lanes, xcd_block_log; };
 constexpr uint32_t kXcdContiguous = 0xFFu;
+// the second batch of a launch (rays == nullptr: none)
+struct TraceSecond { const rt_ray *rays; uint64_t n_bound; rt_hit *hits; const uint32_t *n_dev; };
 #ifndef TRACE_COOP_LEAF
 #define TRACE_COOP_LEAF 1
 #endif
@@ -214,9 +216,15 @@ __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return (floa
 template <bool LDS_STACK, bool ANY, bool WT, bool RESIDENT>
 __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGeom g, TraceTuning tune, const rt_ray *__restrict__ rays, uint64_t n_bound,
                                                   rt_hit *__restrict__ hits, double *__restrict__ t64,
-                                                  uint8_t *__restrict__ any_out, const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ work)
+                                                  uint8_t *__restrict__ any_out, const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ work, TraceSecond second)
 {
-	const uint64_t n = n_dev ? (uint64_t)*n_dev : n_bound;
+	// A launch can take a second batch of rays with its own results (closest hit only): an integrator's connection rays of one
+	// bounce and its path rays of the next are ready at the same time, and one launch over both has one tail where two have two.
+	// The chunks of the second batch follow those of the first; `n` counts rays as if both were padded to whole chunks.
+	const uint64_t n_a = n_dev ? (uint64_t)*n_dev : n_bound;
+	const uint64_t n_b = second.rays ? (second.n_dev ? (uint64_t)*second.n_dev : second.n_bound) : 0;
+	const uint64_t chunks_a = (n_a + 63) >> 6;
+	const uint64_t n = second.rays ? (chunks_a + ((n_b + 63) >> 6)) * 64 : n_a;
 #ifdef TRACE_STATS
 	// diagnostic build only: per-lane trip counts of the three loops (summed into the t64 buffer at the end)
 	unsigned st_ray_steps = 0, st_ray_outer = 0; // node steps and passes of the main loop of the lane's current ray
@@ -311,10 +319,14 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 				else if (chunk_b != ~0ull) mine = chunk_b * 64 + (rank - rem);
 				if (nidle > rem) { cur_chunk = chunk_b; cur_pos = chunk_b != ~0ull ? nidle - rem : 64u; }
 				else cur_pos += nidle;
-				if (!active && mine < n) {
-					const float4 ra = reinterpret_cast<const float4 *>(rays)[2 * mine];
-					const float4 rb = reinterpret_cast<const float4 *>(rays)[2 * mine + 1];
-					ray_id = mine;
+				// which batch the ray belongs to, and where in it (the second batch's flag rides in the top bit of the ray's id)
+				const bool in_b = second.rays != nullptr && mine != ~0ull && (mine >> 6) >= chunks_a;
+				const uint64_t local = in_b ? mine - chunks_a * 64 : mine;
+				if (!active && mine != ~0ull && local < (in_b ? n_b : n_a)) {
+					const float4 *src = reinterpret_cast<const float4 *>(in_b ? second.rays : rays);
+					const float4 ra = src[2 * local];
+					const float4 rb = src[2 * local + 1];
+					ray_id = local | (in_b ? 1ull << 63 : 0ull);
 					ox = ra.x; oy = ra.y; oz = ra.z; tmin_f = ra.w;
 					dx = rb.x; dy = rb.y; dz = rb.z; tfar_f = rb.w;
 					// Box tests run on the direction scaled by a power of two so that its largest component lies in
@@ -631,9 +643,11 @@ __global__ void __launch_bounds__(kBlock, TRACE_WAVES_PER_SIMD) k_trace(DeviceGe
 						h.tri = RT_MISS;
 						h.object = RT_MISS;
 					}
-					reinterpret_cast<uint4 *>(hits)[ray_id] = *reinterpret_cast<uint4 *>(&h);
+					const bool to_b = (ray_id >> 63) != 0;
+					const uint64_t at = ray_id & ~(1ull << 63);
+					reinterpret_cast<uint4 *>(to_b ? second.hits : hits)[at] = *reinterpret_cast<uint4 *>(&h);
 #if !defined(TRACE_STATS) && !defined(TRACE_ENDTIMES)
-					if (t64) t64[ray_id] = best != RT_MISS ? t_best : (double)__int_as_float(0x7f800000);
+					if (t64 && !to_b) t64[at] = best != RT_MISS ? t_best : (double)__int_as_float(0x7f800000);
 #endif
 				}
 				l0_hits = 0;
@@ -690,9 +704,16 @@ inline TraceGrid trace_grid(uint64_t n)
 
 namespace {
 template <bool ANY>
-hipError_t launch_trace(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, uint8_t *d_any, hipStream_t stream, const uint32_t *d_n)
+hipError_t launch_trace(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n_first, rt_hit *d_hits, double *d_t64, uint8_t *d_any, hipStream_t stream, const uint32_t *d_n,
+                        TraceSecond second = TraceSecond{nullptr, 0, nullptr, nullptr})
 {
-	if (n == 0) return hipSuccess;
+	if (second.rays && second.n_bound == 0) second = TraceSecond{nullptr, 0, nullptr, nullptr};
+	if (n_first == 0 && second.rays) { // only the second batch has rays: it is the launch's first
+		d_rays = second.rays; n_first = second.n_bound; d_hits = second.hits; d_n = second.n_dev;
+		second = TraceSecond{nullptr, 0, nullptr, nullptr};
+	}
+	if (n_first == 0) return hipSuccess;
+	const uint64_t n = n_first + (second.rays ? second.n_bound + 64 : 0); // sizes the grid: both batches, the first padded to whole chunks
 	if (g.depth > (uint32_t)kScratchStack) return hipErrorInvalidValue;
 	const TraceGrid tg = trace_grid(n);
 	const bool lds = g.depth <= (uint32_t)kLdsStack;
@@ -724,7 +745,7 @@ hipError_t launch_trace(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, r
 		if (e == hipSuccess) e = hipMemsetAsync(d_work, 0, TraceWork::set_words() * sizeof(uint32_t), stream);
 		if (e != hipSuccess) return e;
 	}
-#define TRACE_LAUNCH(L, W, R) hipLaunchKernelGGL((k_trace<L, ANY, W, R>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, tune, d_rays, n, d_hits, d_t64, d_any, d_n, d_work)
+#define TRACE_LAUNCH(L, W, R) hipLaunchKernelGGL((k_trace<L, ANY, W, R>), dim3(tg.blocks), dim3(kBlock), 0, stream, g, tune, d_rays, n_first, d_hits, d_t64, d_any, d_n, d_work, second)
 #define TRACE_LAUNCH_R(L, W) do { if (resident) TRACE_LAUNCH(L, W, true); else TRACE_LAUNCH(L, W, false); } while (0)
 	if (g.watertight) { if (lds) TRACE_LAUNCH_R(true, true); else TRACE_LAUNCH_R(false, true); }
 	else { if (lds) TRACE_LAUNCH_R(true, false); else TRACE_LAUNCH_R(false, false); }
@@ -742,6 +763,12 @@ hipError_t launch_trace(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, r
 hipError_t launch_trace_closest(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits, double *d_t64, hipStream_t stream, const uint32_t *d_n)
 {
 	return launch_trace<false>(g, d_rays, n, d_hits, d_t64, nullptr, stream, d_n);
+}
+
+hipError_t launch_trace_closest_two(const DeviceGeom &g, const rt_ray *d_rays_a, uint64_t n_a, rt_hit *d_hits_a, const uint32_t *d_n_a,
+                                    const rt_ray *d_rays_b, uint64_t n_b, rt_hit *d_hits_b, const uint32_t *d_n_b, hipStream_t stream)
+{
+	return launch_trace<false>(g, d_rays_a, n_a, d_hits_a, nullptr, nullptr, stream, d_n_a, TraceSecond{d_rays_b, n_b, d_hits_b, d_n_b});
 }
 
 hipError_t launch_trace_any(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n, uint8_t *d_out, hipStream_t stream, const uint32_t *d_n)
