@@ -31,6 +31,7 @@ struct DeviceGeom {
 	uint32_t watertight;         // 0: the reference's triangle test; 1: the watertight test (rt_set_triangle_test)
 	uint32_t surface_rays;       // 1: the rays are an integrator's (set by the render passes on their copy): they end on surfaces, so most
 	                             // node visits find a leaf and the kernel variant that always fetches a node's whole header pays
+	uint32_t ordered_rays;       // 1: the rays of this launch have been ordered by the cell of their origin (ray_bins.h): every XCD takes a contiguous eighth
 	TraceWork *work;             // host side only (kernels ignore it): the context's work counters for the traversal launches, or null
 };
 

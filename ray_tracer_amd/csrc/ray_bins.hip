@@ -43,8 +43,10 @@ __device__ __forceinline__ uint32_t cell_of(const Grid &g, float4 o)
 	return spread3(axis_cell((o.x - g.ox) * g.ix)) | (spread3(axis_cell((o.y - g.oy) * g.iy)) << 1) | (spread3(axis_cell((o.z - g.oz) * g.iz)) << 2);
 }
 
-__global__ void __launch_bounds__(kBinBlock) k_bin_count(const float4 *__restrict__ root_node, const float4 *__restrict__ rays, uint32_t n, uint32_t *__restrict__ counts)
+__global__ void __launch_bounds__(kBinBlock) k_bin_count(const float4 *__restrict__ root_node, const float4 *__restrict__ rays, uint32_t n_bound, const uint32_t *__restrict__ n_dev,
+                                                         uint32_t *__restrict__ counts)
 {
+	const uint32_t n = n_dev ? min(n_bound, *n_dev) : n_bound; // the count may live on the device (a queue of an integrator): n_bound sizes the grid
 	__shared__ uint32_t h[kRayBins];
 	for (int b = threadIdx.x; b < kRayBins; b += kBinBlock) h[b] = 0;
 	__syncthreads();
@@ -71,9 +73,10 @@ __global__ void __launch_bounds__(kRayBins) k_bin_scan(const uint32_t *__restric
 	cursor[threadIdx.x] = before;
 }
 
-__global__ void __launch_bounds__(kBinBlock) k_bin_scatter(const float4 *__restrict__ root_node, const float4 *__restrict__ rays, uint32_t n,
+__global__ void __launch_bounds__(kBinBlock) k_bin_scatter(const float4 *__restrict__ root_node, const float4 *__restrict__ rays, uint32_t n_bound, const uint32_t *__restrict__ n_dev,
                                                            uint32_t *__restrict__ cursor, float4 *__restrict__ sorted, uint32_t *__restrict__ perm)
 {
+	const uint32_t n = n_dev ? min(n_bound, *n_dev) : n_bound;
 	__shared__ uint32_t h[kRayBins]; // first the workgroup's count per cell, then the first slot of its run in that cell
 	for (int b = threadIdx.x; b < kRayBins; b += kBinBlock) h[b] = 0;
 	__syncthreads();
@@ -108,9 +111,10 @@ __global__ void __launch_bounds__(kBinBlock) k_bin_scatter(const float4 *__restr
 	}
 }
 
-__global__ void __launch_bounds__(kBinBlock) k_unbin(const uint32_t *__restrict__ perm, uint32_t n, const uint4 *__restrict__ sorted_hits,
+__global__ void __launch_bounds__(kBinBlock) k_unbin(const uint32_t *__restrict__ perm, uint32_t n_bound, const uint32_t *__restrict__ n_dev, const uint4 *__restrict__ sorted_hits,
                                                      const double *__restrict__ sorted_t64, uint4 *__restrict__ hits, double *__restrict__ t64)
 {
+	const uint32_t n = n_dev ? min(n_bound, *n_dev) : n_bound;
 	const uint64_t i = (uint64_t)blockIdx.x * kBinBlock + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t p = perm[i];
@@ -126,25 +130,25 @@ __global__ void __launch_bounds__(kBinBlock) k_unbin_bytes(const uint32_t *__res
 
 } // namespace
 
-hipError_t bin_rays(const float4 *root_node, const rt_ray *rays, uint32_t n, rt_ray *sorted, uint32_t *perm, uint32_t *counters, hipStream_t stream)
+hipError_t bin_rays(const float4 *root_node, const rt_ray *rays, uint32_t n, rt_ray *sorted, uint32_t *perm, uint32_t *counters, hipStream_t stream, const uint32_t *n_dev)
 {
 	static_assert(sizeof(rt_ray) == 32 && sizeof(rt_hit) == 16, "records are moved as 16-byte pieces");
 	if (n == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(counters, 0, 2 * kRayBins * sizeof(uint32_t), stream);
 	if (e != hipSuccess) return e;
 	const unsigned blocks = (unsigned)(((uint64_t)n + kBinBlock * kBinPer - 1) / (kBinBlock * kBinPer));
-	hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kBinBlock), 0, stream, root_node, reinterpret_cast<const float4 *>(rays), n, counters);
+	hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kBinBlock), 0, stream, root_node, reinterpret_cast<const float4 *>(rays), n, n_dev, counters);
 	hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kRayBins), 0, stream, counters, counters + kRayBins);
-	hipLaunchKernelGGL(k_bin_scatter, dim3(blocks), dim3(kBinBlock), 0, stream, root_node, reinterpret_cast<const float4 *>(rays), n, counters + kRayBins,
+	hipLaunchKernelGGL(k_bin_scatter, dim3(blocks), dim3(kBinBlock), 0, stream, root_node, reinterpret_cast<const float4 *>(rays), n, n_dev, counters + kRayBins,
 	                   reinterpret_cast<float4 *>(sorted), perm);
 	return hipGetLastError();
 }
 
-hipError_t unbin_results(const uint32_t *perm, uint32_t n, const rt_hit *sorted_hits, const double *sorted_t64, rt_hit *hits, double *t64, hipStream_t stream)
+hipError_t unbin_results(const uint32_t *perm, uint32_t n, const rt_hit *sorted_hits, const double *sorted_t64, rt_hit *hits, double *t64, hipStream_t stream, const uint32_t *n_dev)
 {
 	if (n == 0) return hipSuccess;
 	const unsigned blocks = (unsigned)(((uint64_t)n + kBinBlock - 1) / kBinBlock);
-	hipLaunchKernelGGL(k_unbin, dim3(blocks), dim3(kBinBlock), 0, stream, perm, n, reinterpret_cast<const uint4 *>(sorted_hits), sorted_t64,
+	hipLaunchKernelGGL(k_unbin, dim3(blocks), dim3(kBinBlock), 0, stream, perm, n, n_dev, reinterpret_cast<const uint4 *>(sorted_hits), sorted_t64,
 	                   reinterpret_cast<uint4 *>(hits), t64);
 	return hipGetLastError();
 }

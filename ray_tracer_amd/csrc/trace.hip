@@ -726,7 +726,7 @@ hipError_t launch_trace(const DeviceGeom &g, const rt_ray *d_rays, uint64_t n_fi
 	static const char *const force = std::getenv("MI355RT_TRACE_RESIDENT"); // experiments: 0 / 1 overrides the choice
 	if (force && (force[0] == '0' || force[0] == '1')) resident = force[0] == '1';
 	TraceTuning tune = g.tri_stride == 7 ? TraceTuning{16u, 62u, kXcdContiguous} : (g.surface_rays ? TraceTuning{8u, 40u, kXcdContiguous} : TraceTuning{8u, 48u, kXcdContiguous});
-	if (g.surface_rays) tune.xcd_block_log = 5; // an integrator's rays, in pixel order: blocks of 32 chunks to the XCDs in turn
+	if (g.surface_rays && !g.ordered_rays) tune.xcd_block_log = 5; // an integrator's rays, in pixel order: blocks of 32 chunks to the XCDs in turn
 	static const char *const t_refill = std::getenv("MI355RT_TRACE_REFILL"), *const t_lanes = std::getenv("MI355RT_TRACE_NODE_LANES"), // experiments
 	                  *const t_xcd = std::getenv("MI355RT_TRACE_XCD_BLOCK");
 	if (t_refill) tune.refill_min = (uint32_t)std::max(1, std::min(64, std::atoi(t_refill)));

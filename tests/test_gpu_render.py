@@ -103,6 +103,30 @@ def test_cornell_film_matches_committed_oracle_film(ctx, cornell_dir, golden_dir
     compare(ctx.download_film(), want.astype(np.float64), 0.05)
 
 
+@pytest.mark.parametrize("alg", [capi.ALG_NAIVE, capi.ALG_NEE, capi.ALG_MIS])
+def test_later_bounces_traced_in_origin_cell_order_give_the_same_film(ctx, cornell_dir, alg, monkeypatch):
+    """MI355RT_RAY_BINS=1 puts the rays of the later bounces (path and connection rays) in the order of the cells their origins lie in
+    before they are traced and their hits back in queue order (a switch for measurements: an integrator's queues are in pixel order,
+    which is the better order, so it is off by default): the same rays are traced and the film is the same up to the order of the
+    fp32 additions."""
+    mesh, records, cam, oc = oracle.cornell_setup(cornell_dir, 96, 64)
+    ctx.upload_mesh(mesh)
+    ctx.upload_materials(records)
+    ctx.set_camera(cam)
+    films, counts = [], []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MI355RT_RAY_BINS", flag)
+        ctx.render_begin(96, 64, 12, 30, alg, 11)
+        for s in range(0, 12, 5):  # passes that hand paths on to the next
+            ctx.render_pass(s, min(5, 12 - s))
+        ctx.render_sync()
+        films.append(ctx.download_film())
+        st = ctx.stats()
+        counts.append((st["camera_samples"], st["closest_rays"], st["any_rays"]))
+    assert counts[0] == counts[1] and counts[0][1] > 96 * 64 * 12 // 2  # (camera rays that cannot touch the scene are not traced)
+    assert films[0].sum() > 0 and np.allclose(films[0], films[1], rtol=1e-5, atol=1e-9)
+
+
 def test_spectral_sample_counts(ctx, cornell_dir):
     # bands wider than a bin (10 bands of 30 nm), and bands that straddle bins (7 bands)
     for S in (10, 7, 1):
