@@ -4,8 +4,8 @@
   python bench.py --gpus N --steps K --warmup W
 
 Workload (N=1): the Cornell box at 1920x1080 through the NEE+MIS wavefront integrator with 30
-spectral bands.  One step = one batch of `--spp-per-step` samples per pixel (default 64, i.e. 133 M
-camera samples, the batch the wavefront queues are sized for); K steps are timed after W warm-up
+spectral bands.  One step = one batch of `--spp-per-step` samples per pixel (default 128, i.e. 265 M
+camera samples, the batch the wavefront queues are sized for on a GPU with 288 GB); K steps are timed after W warm-up
 steps; value = samples per pixel per second over all GPUs.  With N>1 every rank renders its own
 sample indices of the same image (weak scaling: K steps per rank) into its own film, and the films
 are summed with one RCCL all-reduce inside the timed region.
@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # bytes/s
-PROFILE_STEPS = 18  # steps of the command the committed PMC profile was taken over (python bench.py --no-cpu --no-soup: 2 warm-up + 16 timed)
+PROFILE_STEPS = 10  # steps of the command the committed PMC profile was taken over (python bench.py --no-cpu --no-soup: 2 warm-up + 8 timed)
 
 
 # the closest-hit kernel's instantiations (stack in LDS or in scratch; reference triangle test; cache-resident scene or not) as
@@ -278,11 +278,11 @@ def over_ranks(res, world, dist, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=128)
     ap.add_argument("--cpu-spp", type=int, default=256)
     ap.add_argument("--soup-tris", type=int, default=1000000)
     ap.add_argument("--soup-sigma", type=float, default=0.004)
@@ -413,7 +413,7 @@ def main():
                 "kernel": "k_trace (closest hit)", "kernel_ms_avg": avg_ms, "launches": k["launches"], "launches_per_step": launches_per_step,
                 "kernel_ms_per_step": ms_per_step_in_kernel, "rays": k["items"], "kernel_ms_total": k["ms"],
                 "mrays_per_s_in_kernel": k["items"] / max(k["ms"], 1e-9) / 1e3}
-        default_workload = (nx, ny, spp, args.algorithm) == (1920, 1080, 64, "mis")
+        default_workload = (nx, ny, spp, args.algorithm) == (1920, 1080, 128, "mis")
         tr, tr_file = recorded_traffic("r*_bench_traffic.json", CLOSEST_KERNELS)
         if tr is not None and default_workload:
             # per step, so that the number of launches the profile averaged over and the number timed here cannot disagree: the
