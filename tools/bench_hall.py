@@ -26,7 +26,7 @@ r.cam.film_height = 0.024; r.cam.film_width = 0.024 * nx / ny; r.cam.aperture = 
 r.cam.SetLens(60.0, 0.4); r.cam.set_Camera([0.0, 1.3, 7.5], [0.0, 1.1, 0.0], [0, 1, 0])
 ctx = r.ctx
 alg = {"mis": capi.ALG_MIS, "nee": capi.ALG_NEE, "naive": capi.ALG_NAIVE, "bdpt": capi.ALG_NAIVE_BDPT}[args.algorithm]
-per = max(1, (1 << 27) // (nx * ny))
+per = max(1, (1 << 28) // (nx * ny))  # one batch of the queues where 200 GB of HBM are free
 ctx.set_camera(r.cam)
 ctx.render_begin(nx, ny, args.spp + per, 30, alg, 7)
 ctx.render_pass(0, per); ctx.render_sync()
