@@ -30,7 +30,10 @@ namespace {
 constexpr int kBlock = 256;
 constexpr unsigned kStrideBlocks = 4096; // grid of the kernels that walk through their input in strides
 constexpr uint32_t kMaxLeaf = 4; // triangles per leaf child: a wide node addresses 8 x 4 = 32 triangles
-constexpr float kCostNode = 1.0f, kCostTri = 1.5f; // surface-area heuristic: one interior step, one triangle test
+#ifndef BUILD_COST_TRI
+#define BUILD_COST_TRI 1.5f
+#endif
+constexpr float kCostNode = 1.0f, kCostTri = BUILD_COST_TRI; // surface-area heuristic: one interior step, one triangle test
 
 #define DB_TRY(x)                                                                       \
 	do {                                                                                \
