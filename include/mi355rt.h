@@ -149,6 +149,14 @@ int rt_upload_mesh(rt_context *ctx, const rt_mesh *mesh);
  * environment variable MI355RT_BUILDER=host|device overrides it. */
 typedef enum rt_builder { RT_BUILDER_HOST_SAH = 0, RT_BUILDER_DEVICE_LBVH = 1, RT_BUILDER_AUTO = 2 } rt_builder;
 int rt_set_builder(rt_context *ctx, int builder);
+/* No counterpart in the reference (its tree, bvh.cpp:134-232, stores every polygon once under the box of the whole polygon).
+ * Before either builder runs, the next rt_upload_mesh cuts the references of triangles whose boxes waste much space -- long thin
+ * triangles lying diagonally: braces, cables, roof edges -- into several references with the boxes of the pieces (Karras and Aila,
+ * HPG 2013, section 4).  `budget` is the number of additional references the whole scene may get, as a fraction of its fan
+ * triangles (default 0.25; 0 switches the cutting off; scenes below 4096 triangles are never cut).  Hits, ids and t do not depend
+ * on it.  rt_get_reference_cutting reports what the last upload did: triangles that were cut, references added. */
+int rt_set_reference_cutting(rt_context *ctx, double budget);
+int rt_get_reference_cutting(rt_context *ctx, uint64_t *cut_triangles, uint64_t *extra_references);
 /* Which ray-triangle test the traversal kernels (and the direct light-polygon test of the NEE integrator) run; takes effect at once.
  * RT_TRIANGLE_REFERENCE (default): ConvexPolygon::HitTriangle as the reference writes it (object.cpp:238-253) -- distance to the
  *   plane of the polygon's first three vertices, three cross products, strict `> 0`: ids and t identical to the reference's
@@ -341,6 +349,15 @@ int rt_get_wide_bvh(rt_context *ctx, rt_wide_node *nodes, uint64_t *n_nodes, uin
  * its vertices' box: this box holds every point that test can accept, so that the closest hit found through the tree is the one
  * a loop over all polygons (HittableList::Hit, hittablelist.cpp:3-17) finds. */
 void rt_accept_region_box(const double a[3], const double b[3], const double c[3], const double nf[3], double lo[3], double hi[3]);
+/* What rt_upload_mesh's cutting of long triangles (rt_set_reference_cutting) does to a mesh, on the host alone (no device needed;
+ * for tests).  A triangle that is cut keeps its own reference with the box of its first piece (`first`, ordered by triangle) and
+ * gets one additional reference per further piece (`extra`).  Pass NULL arrays to query the counts; min_tris: scenes with fewer
+ * fan triangles are left alone (rt_upload_mesh uses 4096).  No counterpart in the reference. */
+typedef struct rt_reference {
+	uint32_t tri;         /* fan triangle */
+	float lo[3], hi[3];   /* box of the piece */
+} rt_reference;
+int rt_cut_references(const rt_mesh *mesh, double budget, uint32_t min_tris, rt_reference *first, uint64_t *n_first, rt_reference *extra, uint64_t *n_extra);
 /* replaces: BiliteralFilter::FilterImage (filter.cpp:13-51; window / sigma_d / sigma_r are the public fields of filter.h:17-27).
  * rgba, out: width * height * 4 doubles, row major, as Filter::orig_img / Filter::result.  Host buffers. */
 int rt_filter_bilateral(rt_context *ctx, const double *rgba, int width, int height, int window, double sigma_d, double sigma_r, double *out);

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MI355RT_LIB") or os.path.join(os.path.dirname(os.path
 
 # every symbol include/mi355rt.h declares
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_triangle_test", "rt_group_set_triangle_test", "rt_set_environment", "rt_upload_materials", "rt_upload_material_graphs", "rt_set_camera", "rt_clear",
+    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_mesh", "rt_set_builder", "rt_set_reference_cutting", "rt_get_reference_cutting", "rt_cut_references", "rt_set_triangle_test", "rt_group_set_triangle_test", "rt_set_environment", "rt_upload_materials", "rt_upload_material_graphs", "rt_set_camera", "rt_clear",
     "rt_trace_closest", "rt_trace_closest_static", "rt_trace_any", "rt_trace_closest_device", "rt_trace_any_device", "rt_render_begin",
     "rt_render_pass", "rt_render_sync", "rt_download_film", "rt_download_preview", "rt_film_device_ptr",
     "rt_group_create", "rt_group_destroy", "rt_group_last_error", "rt_group_size", "rt_group_context", "rt_group_upload_mesh",
@@ -32,6 +32,7 @@ RAY_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("oz", "f4"), ("tmin", "f4"),
 HIT_DTYPE = np.dtype([("t", "f4"), ("prim", "u4"), ("tri", "u4"), ("object", "u4")])
 BVH2_NODE_DTYPE = np.dtype([("lo0", "f4", 3), ("hi0", "f4", 3), ("lo1", "f4", 3), ("hi1", "f4", 3),
                             ("child0", "i4"), ("child1", "i4"), ("pad", "u4", 2)])
+REFERENCE_DTYPE = np.dtype([("tri", "u4"), ("lo", "f4", 3), ("hi", "f4", 3)])
 WIDE_NODE_DTYPE = np.dtype([("org", "f4", 3), ("e", "u1", 3), ("imask", "u1"), ("child_base", "u4"), ("tri_base", "u4"), ("meta", "u1", 8),
                             ("qlo", "u1", (3, 8)), ("qhi", "u1", (3, 8)), ("pad", "u1", 48)])
 assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 16 and BVH2_NODE_DTYPE.itemsize == 64 and WIDE_NODE_DTYPE.itemsize == 128
@@ -108,6 +109,9 @@ def load():
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_upload_mesh.argtypes = [vp, C.POINTER(Mesh)]
     lib.rt_set_builder.argtypes = [vp, C.c_int]
+    lib.rt_set_reference_cutting.argtypes = [vp, C.c_double]
+    lib.rt_get_reference_cutting.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.rt_cut_references.argtypes = [C.POINTER(Mesh), C.c_double, C.c_uint32, vp, C.POINTER(C.c_uint64), vp, C.POINTER(C.c_uint64)]
     lib.rt_set_triangle_test.argtypes = [vp, C.c_int]
     lib.rt_group_set_triangle_test.argtypes = [vp, C.c_int]
     lib.rt_upload_material_graphs.argtypes = [vp, vp]
@@ -164,6 +168,28 @@ def load():
     return lib
 
 
+def cut_references(mesh, budget=0.25, min_tris=4096):
+    """what upload_mesh's cutting of long triangles does to `mesh` (host arithmetic only, no device): (first, extra) as
+    REFERENCE_DTYPE arrays -- a cut triangle's own reference with the box of its first piece, and its additional references"""
+    lib = load()
+    v = np.ascontiguousarray(mesh["v"], dtype=np.float64).reshape(-1, 3)
+    vt = np.ascontiguousarray(mesh["vt"], dtype=np.float64).reshape(-1, 3)
+    vn = np.ascontiguousarray(mesh["vn"], dtype=np.float64).reshape(-1, 3)
+    corners = np.ascontiguousarray(mesh["corners"], dtype=np.int64).reshape(-1, 3)
+    fb = np.ascontiguousarray(mesh["face_begin"], dtype=np.uint64)
+    ob = np.ascontiguousarray(mesh["object_begin"], dtype=np.uint64)
+    m = Mesh(_ptr(v), len(v), _ptr(vt), len(vt), _ptr(vn), len(vn), _ptr(corners), _ptr(fb), len(fb) - 1, _ptr(ob), len(ob) - 1)
+    nf, ne = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.rt_cut_references(C.byref(m), float(budget), int(min_tris), None, C.byref(nf), None, C.byref(ne))
+    if rc != 0:
+        raise BackendError(rc, "rt_cut_references")
+    first, extra = np.zeros(nf.value, dtype=REFERENCE_DTYPE), np.zeros(ne.value, dtype=REFERENCE_DTYPE)
+    rc = lib.rt_cut_references(C.byref(m), float(budget), int(min_tris), _ptr(first), C.byref(nf), _ptr(extra), C.byref(ne))
+    if rc != 0:
+        raise BackendError(rc, "rt_cut_references")
+    return first, extra
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
@@ -205,6 +231,16 @@ class Context:
         ob = np.ascontiguousarray(mesh["object_begin"], dtype=np.uint64)
         m = Mesh(_ptr(v), len(v), _ptr(vt), len(vt), _ptr(vn), len(vn), _ptr(corners), _ptr(fb), len(fb) - 1, _ptr(ob), len(ob) - 1)
         self._check(self.lib.rt_upload_mesh(self.h, C.byref(m)))
+
+    def set_reference_cutting(self, budget):
+        """additional references the next uploads may give long triangles, as a fraction of the scene's triangles (0: none)"""
+        self._check(self.lib.rt_set_reference_cutting(self.h, float(budget)))
+
+    def reference_cutting(self):
+        """(triangles cut, references added) by the last upload"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.rt_get_reference_cutting(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_builder(self, builder):
         """BUILDER_HOST_SAH (default) or BUILDER_DEVICE_LBVH for the next upload_mesh"""

@@ -17,6 +17,7 @@
 #include "filter.h"
 #include "accept_region.h"
 #include "parallel_for.h"
+#include "presplit.h"
 #include "ray_bins.h"
 #include "trace.h"
 
@@ -272,6 +273,17 @@ try {
 		b[0] = v1[0]; b[1] = v1[1]; b[2] = v1[2]; b[3] = v2[0]; b[4] = v2[1]; b[5] = v2[2];
 	};
 	std::vector<uint32_t> tri_leaf(nt);
+	// references of long triangles are cut into pieces first (presplit.h): both builders build over the references
+	Presplit cut;
+	{
+		PresplitOptions po;
+		po.budget = (float)ctx->cut_budget;
+		if (const char *s = std::getenv("MI355RT_PRESPLIT")) po.budget = (float)std::atof(s); // experiments
+		presplit(hs, po, cut);
+	}
+	ctx->cut_triangles = cut.first.size();
+	ctx->extra_references = cut.extra.size();
+	lap("long triangles cut");
 	if (builder == RT_BUILDER_DEVICE_LBVH) {
 		// records go up in fan order; the device builds the tree and reorders them
 		void *d_a = nullptr, *d_b = nullptr;
@@ -290,7 +302,7 @@ try {
 			}), "upload of the triangle halves");
 		lap("triangle halves");
 		if (ok && build_bvh_device((const double *)d_a, (const double *)d_b, (const uint32_t *)ctx->d_tri_face, (const uint32_t *)ctx->d_face_object,
-		                           (uint32_t)nt, ctx->stream, built, err) != hipSuccess) {
+		                           (uint32_t)nt, &cut, ctx->stream, built, err) != hipSuccess) {
 			ctx->error = err;
 			ok = false;
 		}
@@ -303,16 +315,16 @@ try {
 			ctx->d_tri = built.tri;
 			ctx->geom.tri_stride = built.tri_stride;
 			ctx->d_leaf_tri = built.leaf_tri;
-			ctx->device_bytes += (uint64_t)built.n_nodes * sizeof(WideNode) + nt * (16 * (uint64_t)built.tri_stride + 4);
+			ctx->device_bytes += (uint64_t)built.n_nodes * sizeof(WideNode) + (uint64_t)built.n_refs * (16 * (uint64_t)built.tri_stride + 4);
 			ctx->bvh = Bvh2();
 			ctx->wide = BvhWide();
 			ctx->wide.depth = built.depth;
-			ctx->wide.tri_index.resize(nt);
+			ctx->wide.tri_index.resize(built.n_refs);
 			ctx->bvh.build_seconds = built.seconds;
 			ctx->bvh.depth = built.depth;
 			ctx->built_on_device = true;
 			ctx->device_nodes = built.n_nodes;
-			ok = !ctx->fail_hip(hipMemcpy(ctx->wide.tri_index.data(), built.leaf_tri, nt * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy(leaf order)") &&
+			ok = !ctx->fail_hip(hipMemcpy(ctx->wide.tri_index.data(), built.leaf_tri, (size_t)built.n_refs * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy(leaf order)") &&
 			     !ctx->fail_hip(hipMemcpy(tri_leaf.data(), built.tri_leaf, nt * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy(triangle positions)");
 			(void)hipFree(built.tri_leaf);
 		}
@@ -333,22 +345,23 @@ try {
 		opt.optimal_cut = triangle_record_stride(nt) == 8 ? 1 : 0;
 		if (const char *s = std::getenv("MI355RT_WIDE_CUT")) opt.optimal_cut = std::atoi(s);        // experiments
 		if (const char *s = std::getenv("MI355RT_WIDE_COST_TRI")) opt.wide_cost_tri = (float)std::atof(s);
-		build_bvh(ctx->host, opt, ctx->bvh, ctx->wide);
+		build_bvh(ctx->host, opt, &cut, ctx->bvh, ctx->wide);
 		ctx->built_on_device = false;
 		ctx->device_nodes = ctx->wide.nodes.size();
 		if (ctx->wide.depth > kTraceMaxDepth) {
 			ctx->free_geometry();
 			return set_err(ctx, RT_ERR_MESH, "rt_upload_mesh: the tree is deeper than the traversal stack (" + std::to_string(ctx->wide.depth) + " levels, limit " + std::to_string(kTraceMaxDepth) + ")");
 		}
-		const uint32_t stride = triangle_record_stride(nt);
+		const uint64_t n_refs = ctx->wide.tri_index.size(); // the triangles, plus the additional pieces of those that were cut
+		const uint32_t stride = triangle_record_stride(n_refs);
 		ctx->geom.tri_stride = stride;
 		const size_t rec_bytes = 16 * (size_t)stride;
-		bool recs_ok = !ctx->fail_hip(hipMalloc(&ctx->d_tri, rec_bytes * std::max<uint64_t>(nt, 1)), "hipMalloc");
-		if (recs_ok) ctx->device_bytes += rec_bytes * std::max<uint64_t>(nt, 1);
-		recs_ok = recs_ok && !ctx->fail_hip(upload_generated(ctx->pinned, ctx->d_tri, nt, rec_bytes, ctx->stream, [&](size_t li_begin, size_t li_end, char *out) {
+		bool recs_ok = !ctx->fail_hip(hipMalloc(&ctx->d_tri, rec_bytes * std::max<uint64_t>(n_refs, 1)), "hipMalloc");
+		if (recs_ok) ctx->device_bytes += rec_bytes * std::max<uint64_t>(n_refs, 1);
+		for (uint64_t li = n_refs; li-- > 0;) tri_leaf[ctx->wide.tri_index[li]] = (uint32_t)li; // a cut triangle: the first of its leaves
+		recs_ok = recs_ok && !ctx->fail_hip(upload_generated(ctx->pinned, ctx->d_tri, n_refs, rec_bytes, ctx->stream, [&](size_t li_begin, size_t li_end, char *out) {
 			for (size_t li = li_begin; li < li_end; li++) { // leaf-ordered records
 				const uint32_t t = ctx->wide.tri_index[li];
-				tri_leaf[t] = (uint32_t)li;
 				double *rec = reinterpret_cast<double *>(out + rec_bytes * (li - li_begin));
 				fill_halves(rec, rec + 6, t);
 				const uint32_t meta[4] = {t, hs.tri_face[t], hs.face_object[hs.tri_face[t]], 0u};
@@ -386,6 +399,22 @@ try {
 	if (!ctx) return RT_ERR_INVALID;
 	if (builder != RT_BUILDER_HOST_SAH && builder != RT_BUILDER_DEVICE_LBVH && builder != RT_BUILDER_AUTO) return set_err(ctx, RT_ERR_INVALID, "rt_set_builder: unknown builder");
 	ctx->builder = builder;
+	return RT_OK;
+} RT_CATCH(ctx)
+
+int rt_set_reference_cutting(rt_context *ctx, double budget)
+try {
+	if (!ctx) return RT_ERR_INVALID;
+	if (!(budget >= 0.0 && budget <= 4.0)) return set_err(ctx, RT_ERR_INVALID, "rt_set_reference_cutting: the budget is a fraction of the scene's triangles between 0 and 4");
+	ctx->cut_budget = budget;
+	return RT_OK;
+} RT_CATCH(ctx)
+
+int rt_get_reference_cutting(rt_context *ctx, uint64_t *cut_triangles, uint64_t *extra_references)
+try {
+	if (!ctx) return RT_ERR_INVALID;
+	if (cut_triangles) *cut_triangles = ctx->cut_triangles;
+	if (extra_references) *extra_references = ctx->extra_references;
 	return RT_OK;
 } RT_CATCH(ctx)
 
@@ -562,6 +591,25 @@ void rt_accept_region_box(const double a[3], const double b[3], const double c[3
 {
 	accept_region_box(a, b, c, nf, lo, hi);
 }
+
+int rt_cut_references(const rt_mesh *mesh, double budget, uint32_t min_tris, rt_reference *first, uint64_t *n_first, rt_reference *extra, uint64_t *n_extra)
+try {
+	static_assert(sizeof(rt_reference) == sizeof(SplitRef), "the same record");
+	if (!mesh || !n_first || !n_extra || !(budget >= 0.0)) return RT_ERR_INVALID;
+	HostScene hs;
+	std::string err;
+	if (!hs.build(*mesh, err)) return RT_ERR_MESH;
+	PresplitOptions po;
+	po.budget = (float)budget;
+	po.min_tris = min_tris;
+	Presplit cut;
+	presplit(hs, po, cut);
+	if (first && *n_first >= cut.first.size()) std::memcpy(first, cut.first.data(), cut.first.size() * sizeof(SplitRef));
+	if (extra && *n_extra >= cut.extra.size()) std::memcpy(extra, cut.extra.data(), cut.extra.size() * sizeof(SplitRef));
+	*n_first = cut.first.size();
+	*n_extra = cut.extra.size();
+	return RT_OK;
+} catch (...) { return RT_ERR_INVALID; }
 
 int rt_trace_closest_device(rt_context *ctx, const void *d_rays, uint64_t n, void *d_hits, void *d_t64, void *stream)
 try {

@@ -1,5 +1,6 @@
 #include "bvh_builder.h"
 #include "accept_region.h"
+#include "presplit.h"
 
 #include <algorithm>
 #include <atomic>
@@ -58,6 +59,7 @@ struct Builder {
 	const BvhBuildOptions &opt;
 	std::vector<Box> prim_box;
 	std::vector<float> centroid; // 3 per prim
+	std::vector<uint32_t> prim_tri; // prim (reference) -> fan triangle: the identity, followed by the additional references of triangles that were cut
 	std::vector<uint32_t> idx;
 	std::vector<TempNode> temp;
 	std::atomic<uint32_t> next_node{0};
@@ -177,7 +179,7 @@ struct Flattener {
 		const TempNode &tn = b.temp[t];
 		if (tn.left < 0) {
 			uint32_t first = (uint32_t)out.tri_index.size();
-			for (uint32_t i = 0; i < tn.count; i++) out.tri_index.push_back(b.idx[tn.first + i]);
+			for (uint32_t i = 0; i < tn.count; i++) out.tri_index.push_back(b.prim_tri[b.idx[tn.first + i]]);
 			out.n_leaves++;
 			return make_leaf_link(first, tn.count);
 		}
@@ -370,7 +372,7 @@ struct WideFlattener {
 			} else {
 				const uint32_t off = (uint32_t)out.tri_index.size() - nd.tri_base;
 				nd.meta[sl] = (uint8_t)((c.count << 5) | off);
-				for (uint32_t k = 0; k < c.count; k++) out.tri_index.push_back(b.idx[c.first + k]);
+				for (uint32_t k = 0; k < c.count; k++) out.tri_index.push_back(b.prim_tri[b.idx[c.first + k]]);
 			}
 		}
 		nd.child_base = (uint32_t)out.nodes.size();
@@ -389,7 +391,7 @@ struct WideFlattener {
 
 } // namespace
 
-void build_bvh(const HostScene &scene, const BvhBuildOptions &opt_in, Bvh2 &out, BvhWide &wide)
+void build_bvh(const HostScene &scene, const BvhBuildOptions &opt_in, const Presplit *cut, Bvh2 &out, BvhWide &wide)
 {
 	auto t_start = std::chrono::steady_clock::now();
 	BvhBuildOptions opt = opt_in;
@@ -419,9 +421,11 @@ void build_bvh(const HostScene &scene, const BvhBuildOptions &opt_in, Bvh2 &out,
 		return;
 	}
 	Builder b(opt);
-	b.prim_box.resize(n);
-	b.centroid.resize(3 * n);
-	b.idx.resize(n);
+	const uint64_t m = n + (cut ? cut->extra.size() : 0); // references
+	b.prim_box.resize(m);
+	b.centroid.resize(3 * m);
+	b.prim_tri.resize(m);
+	b.idx.resize(m);
 	for (uint64_t t = 0; t < n; t++) {
 		const double *v0, *v1, *v2;
 		scene.tri_vertices(t, v0, v1, v2);
@@ -437,16 +441,31 @@ void build_bvh(const HostScene &scene, const BvhBuildOptions &opt_in, Bvh2 &out,
 			b.centroid[3 * t + a] = (float)(0.5 * (mn + mx));
 		}
 		b.prim_box[t] = bx;
+		b.prim_tri[t] = (uint32_t)t;
 		b.idx[t] = (uint32_t)t;
 	}
-	b.temp.resize(2 * n);
+	if (cut) {
+		// a triangle that was cut keeps its reference with the box of its first piece; the other pieces are references of their own
+		auto place = [&](uint64_t prim, const SplitRef &r) {
+			for (int a = 0; a < 3; a++) {
+				b.prim_box[prim].lo[a] = r.lo[a];
+				b.prim_box[prim].hi[a] = r.hi[a];
+				b.centroid[3 * prim + a] = 0.5f * (r.lo[a] + r.hi[a]);
+			}
+			b.prim_tri[prim] = r.tri;
+			b.idx[prim] = (uint32_t)prim;
+		};
+		for (const SplitRef &r : cut->first) place(r.tri, r);
+		for (size_t k = 0; k < cut->extra.size(); k++) place(n + k, cut->extra[k]);
+	}
+	b.temp.resize(2 * m);
 	int hw = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();
 	b.max_threads = std::max(1, std::min(hw, 32));
 	uint32_t root = b.alloc_node();
-	b.build(root, 0, (uint32_t)n, 0);
+	b.build(root, 0, (uint32_t)m, 0);
 
-	out.nodes.reserve(n);
-	out.tri_index.reserve(n);
+	out.nodes.reserve(m);
+	out.tri_index.reserve(m);
 	Flattener fl{b, out};
 	if (b.temp[root].left < 0) {
 		// the whole scene fits one leaf: a root whose second child is an empty box
@@ -463,12 +482,12 @@ void build_bvh(const HostScene &scene, const BvhBuildOptions &opt_in, Bvh2 &out,
 	} else {
 		fl.emit((int32_t)root, 0);
 	}
-	wide.nodes.reserve(n / 2 + 16);
-	wide.tri_index.reserve(n);
+	wide.nodes.reserve(m / 2 + 16);
+	wide.tri_index.reserve(m);
 	wide.nodes.resize(1);
-	WideCut cut;
-	if (opt.optimal_cut) cut.solve(b, b.next_node.load(), opt.wide_cost_node, opt.wide_cost_tri);
-	WideFlattener wf{b, wide, cut};
+	WideCut wide_cut;
+	if (opt.optimal_cut) wide_cut.solve(b, b.next_node.load(), opt.wide_cost_node, opt.wide_cost_tri);
+	WideFlattener wf{b, wide, wide_cut};
 	wf.emit((int32_t)root, 0, 1);
 	out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 }

@@ -12,7 +12,7 @@ namespace mi355rt {
 
 struct Bvh2 {
 	std::vector<rt_bvh2_node> nodes;   // node 0 = root, preorder
-	std::vector<uint32_t> tri_index;   // leaf order -> fan triangle id
+	std::vector<uint32_t> tri_index;   // leaf order -> fan triangle id (a triangle whose reference was cut appears once per piece, presplit.h)
 	uint32_t depth = 0;                // interior levels on the longest root-to-leaf path
 	uint64_t n_leaves = 0;
 	double build_seconds = 0.0;
@@ -60,12 +60,14 @@ static_assert(sizeof(WideNode) == 128, "one node per 128-byte line");
 
 struct BvhWide {
 	std::vector<WideNode> nodes;     // node 0 = root
-	std::vector<uint32_t> tri_index; // leaf order -> fan triangle id
+	std::vector<uint32_t> tri_index; // leaf order -> fan triangle id (once per piece for a triangle whose reference was cut)
 	uint32_t depth = 0;              // nodes on the longest root-to-leaf path
 };
 
-// builds the binary tree once and flattens it twice (out2 for introspection / work counting, wide for the device)
-void build_bvh(const HostScene &scene, const BvhBuildOptions &opt, Bvh2 &out2, BvhWide &wide);
+// builds the binary tree once and flattens it twice (out2 for introspection / work counting, wide for the device);
+// cut: references of long triangles cut into pieces (presplit.h), or null
+struct Presplit;
+void build_bvh(const HostScene &scene, const BvhBuildOptions &opt, const Presplit *cut, Bvh2 &out2, BvhWide &wide);
 
 inline int32_t make_leaf_link(uint32_t first, uint32_t count) { return ~(int32_t)(((count - 1u) << 27) | first); }
 

@@ -26,6 +26,8 @@ struct rt_context {
 	mi355rt::BvhWide wide; // the tree the device walks
 	bool has_mesh = false, has_materials = false, has_camera = false;
 	int builder = RT_BUILDER_AUTO;
+	double cut_budget = 0.25;                          // rt_set_reference_cutting
+	uint64_t cut_triangles = 0, extra_references = 0;  // what the last upload cut (presplit.h)
 	int triangle_test = RT_TRIANGLE_REFERENCE;
 	bool built_on_device = false;
 	uint64_t device_nodes = 0;     // nodes of the tree in HBM

@@ -3,8 +3,10 @@
 // Stands in for SAHBVHNode::SAHBVHNode (reference bvh.cpp:134-232) when the scene is large: the topology is free
 // to differ from the reference's, because a closest hit does not depend on it (ties in t aside).
 //
-// Stages (n = fan triangles, all buffers in HBM):
+// Stages (n = fan triangles, m = references: the triangles plus the additional pieces of those the host has cut, presplit.h;
+// all buffers in HBM):
 //   k_tri_boxes     fp64 vertices -> fp32 boxes rounded outward, scene bounds of the box centres (ordered-int atomics)
+//   k_place_refs    boxes of the pieces: a cut triangle's own reference gets its first piece's box, the others are references n .. m - 1
 //   k_morton        63-bit Morton key of each box centre (21 bits per axis)
 //   radix sort      eight stable passes over eight bits of the key (k_sort_hist, k_scan_*, k_sort_scatter)
 //   k_hierarchy     binary radix tree over the sorted keys; ties between equal keys are broken by position
@@ -21,6 +23,7 @@
 #include "accept_region.h"
 #include "bvh_builder.h"
 #include "device_build.h"
+#include "presplit.h"
 #include "trace.h"
 
 namespace mi355rt {
@@ -104,6 +107,19 @@ __global__ void __launch_bounds__(kBlock) k_tri_boxes(const double2 *__restrict_
 			atomicMax(&bounds[3 + threadIdx.x], float_to_ordered(hi));
 		}
 	}
+}
+
+// ref: piece k of the list goes to reference at[k] (a cut triangle's own slot, or n + k for the additional ones)
+struct RefBox { float lo[3], hi[3]; };
+__global__ void __launch_bounds__(kBlock) k_place_refs(const RefBox *__restrict__ pieces, const uint32_t *__restrict__ at, uint32_t base, uint32_t count, Box4 *__restrict__ boxes)
+{
+	const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+	if (k >= count) return;
+	const RefBox r = pieces[k];
+	Box4 b;
+	b.lo = make_float4(r.lo[0], r.lo[1], r.lo[2], 0.0f);
+	b.hi = make_float4(r.hi[0], r.hi[1], r.hi[2], 0.0f);
+	boxes[at ? at[k] : base + k] = b;
 }
 
 __device__ __forceinline__ uint64_t spread21(uint64_t x)
@@ -633,12 +649,14 @@ __global__ void __launch_bounds__(kBlock) k_collapse(const BinNode *__restrict__
 
 __global__ void __launch_bounds__(kBlock) k_gather(const double2 *__restrict__ a_in, const double2 *__restrict__ b_in,
                                                    const uint32_t *__restrict__ tri_face, const uint32_t *__restrict__ face_object,
-                                                   const uint32_t *__restrict__ leaf_tri, uint32_t n, uint32_t stride, double2 *__restrict__ rec_out,
-                                                   uint32_t *__restrict__ tri_leaf)
+                                                   const uint32_t *__restrict__ leaf_ref, const uint32_t *__restrict__ extra_tri, uint32_t n, uint32_t m,
+                                                   uint32_t stride, double2 *__restrict__ rec_out, uint32_t *__restrict__ leaf_tri, uint32_t *__restrict__ tri_leaf)
 {
 	const uint32_t li = blockIdx.x * kBlock + threadIdx.x;
-	if (li >= n) return;
-	const uint32_t t = leaf_tri[li];
+	if (li >= m) return;
+	const uint32_t ref = leaf_ref[li];
+	const uint32_t t = ref < n ? ref : extra_tri[ref - n]; // the triangle's own reference, or an additional piece of it
+	leaf_tri[li] = t;
 	double2 *rec = rec_out + (size_t)stride * li;
 	for (int k = 0; k < 3; k++) {
 		rec[k] = a_in[3 * (size_t)t + k];
@@ -647,7 +665,7 @@ __global__ void __launch_bounds__(kBlock) k_gather(const double2 *__restrict__ a
 	const uint32_t face = tri_face[t];
 	reinterpret_cast<uint4 *>(rec)[6] = make_uint4(t, face, face_object[face], 0u);
 	if (stride > 7) rec[7] = make_double2(0.0, 0.0);
-	tri_leaf[t] = li;
+	if (ref < n) tri_leaf[t] = li; // every triangle has exactly one reference of its own
 }
 
 template <class T>
@@ -662,10 +680,13 @@ hipError_t dalloc(T *&p, size_t count, std::vector<void *> &owned)
 } // namespace
 
 hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan, const uint32_t *d_tri_face, const uint32_t *d_face_object,
-                            uint32_t n, hipStream_t stream, DeviceBvh &out, std::string &err)
+                            uint32_t n_tris, const Presplit *cut, hipStream_t stream, DeviceBvh &out, std::string &err)
 {
 	out = DeviceBvh();
-	if (n < 2) { err = "build_bvh_device: needs at least two triangles"; return hipErrorInvalidValue; }
+	if (n_tris < 2) { err = "build_bvh_device: needs at least two triangles"; return hipErrorInvalidValue; }
+	const size_t n_first = cut ? cut->first.size() : 0, n_extra = cut ? cut->extra.size() : 0;
+	if ((uint64_t)n_tris + n_extra > 0x7FFFFFFFull) { err = "build_bvh_device: too many references"; return hipErrorInvalidValue; }
+	const uint32_t n = n_tris + (uint32_t)n_extra; // references: the leaves of the tree
 	auto t_start = std::chrono::steady_clock::now();
 	std::vector<void *> tmp; // scratch freed on every exit path
 	struct Cleanup {
@@ -706,7 +727,30 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	// ---- boxes, keys, sort
 	const int init_bounds[6] = {0x7F7FFFFF, 0x7F7FFFFF, 0x7F7FFFFF, (int)0x80800000, (int)0x80800000, (int)0x80800000}; // +FLT_MAX x3, ordered(-FLT_MAX) x3
 	DB_TRY(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
-	hipLaunchKernelGGL(k_tri_boxes, dim3(std::min(blocks_n, kStrideBlocks)), dim3(kBlock), 0, stream, (const double2 *)d_tri_a_fan, (const double2 *)d_tri_b_fan, n, tri_boxes, bounds);
+	hipLaunchKernelGGL(k_tri_boxes, dim3(std::min((n_tris + kBlock - 1) / kBlock, kStrideBlocks)), dim3(kBlock), 0, stream, (const double2 *)d_tri_a_fan, (const double2 *)d_tri_b_fan, n_tris, tri_boxes, bounds);
+	uint32_t *extra_tri = nullptr;
+	if (n_first + n_extra) {
+		// the pieces' boxes lie inside the boxes just computed: the bounds of the centres stand
+		static_assert(sizeof(SplitRef) == 28 && sizeof(RefBox) == 24, "a piece is its triangle and six floats");
+		std::vector<RefBox> h_box(n_first + n_extra);
+		std::vector<uint32_t> h_tri(n_first + n_extra);
+		for (size_t k = 0; k < n_first + n_extra; k++) {
+			const SplitRef &r = k < n_first ? cut->first[k] : cut->extra[k - n_first];
+			if (r.tri >= n_tris) { err = "build_bvh_device: a piece names a triangle the scene does not have"; return hipErrorInvalidValue; }
+			for (int a = 0; a < 3; a++) { h_box[k].lo[a] = r.lo[a]; h_box[k].hi[a] = r.hi[a]; }
+			h_tri[k] = r.tri;
+		}
+		RefBox *d_box = nullptr;
+		uint32_t *d_tri_of = nullptr;
+		DB_TRY(dalloc(d_box, h_box.size(), tmp));
+		DB_TRY(dalloc(d_tri_of, h_tri.size(), tmp));
+		DB_TRY(hipMemcpyAsync(d_box, h_box.data(), h_box.size() * sizeof(RefBox), hipMemcpyHostToDevice, stream));
+		DB_TRY(hipMemcpyAsync(d_tri_of, h_tri.data(), h_tri.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+		if (n_first) hipLaunchKernelGGL(k_place_refs, dim3((unsigned)((n_first + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_box, d_tri_of, 0u, (uint32_t)n_first, tri_boxes);
+		if (n_extra) hipLaunchKernelGGL(k_place_refs, dim3((unsigned)((n_extra + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_box + n_first, (const uint32_t *)nullptr, n_tris, (uint32_t)n_extra, tri_boxes);
+		DB_TRY(hipStreamSynchronize(stream)); // the host arrays go out of scope
+		extra_tri = d_tri_of + n_first;
+	}
 	hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(kBlock), 0, stream, tri_boxes, n, bounds, keys, vals);
 	{
 		const uint32_t n_tiles = (n + kSortTile - 1) / kSortTile, m = 256u * n_tiles, scan_tiles = (m + kScanTile - 1) / kScanTile;
@@ -789,14 +833,13 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	double2 *rec_out = nullptr;
 	hipError_t e = dalloc(nodes_out, n_nodes, keep);
 	if (e == hipSuccess) e = dalloc(leaf_out, n, keep);
-	if (e == hipSuccess) e = dalloc(tri_leaf, n, keep);
+	if (e == hipSuccess) e = dalloc(tri_leaf, n_tris, keep);
 	out.tri_stride = triangle_record_stride(n);
 	if (e == hipSuccess) e = dalloc(rec_out, (size_t)out.tri_stride * n, keep);
 	if (e == hipSuccess) e = hipMemcpyAsync(nodes_out, wide, sizeof(WideNode) * n_nodes, hipMemcpyDeviceToDevice, stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(leaf_out, leaf_tri, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream);
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(k_gather, dim3(blocks_n), dim3(kBlock), 0, stream, (const double2 *)d_tri_a_fan, (const double2 *)d_tri_b_fan, d_tri_face, d_face_object,
-		                   leaf_tri, n, out.tri_stride, rec_out, tri_leaf);
+		                   leaf_tri, extra_tri, n_tris, n, out.tri_stride, rec_out, leaf_out, tri_leaf);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -810,6 +853,7 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 	out.tri_leaf = tri_leaf;
 	out.tri = rec_out;
 	out.n_nodes = n_nodes;
+	out.n_refs = n;
 	out.depth = depth;
 	out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 	return hipSuccess;

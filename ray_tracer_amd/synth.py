@@ -107,11 +107,14 @@ def _material_json(name, node_type, light=False, **arrays):
             "connections": [{"input_node": 1, "input_slot": "BSDF", "output_node": 2, "output_slot": "BSDF"}]}
 
 
-def atrium(directory, detail=1.0, seed=7):
+def atrium(directory, detail=1.0, seed=7, long_polygons=False):
     """Writes a hall-like project (model.obj, materials.json, objmatmap.json) into `directory` and returns their paths and the
     polygon count.  At detail 1: 31 objects, about 320 k polygons (170 k quads, of which 58 k are not planar, 150 k triangles; 490 k fan
     triangles): a displaced floor and side walls (quads that are not planar), flat walls and ceiling (quads), two rows of fluted columns (quads), displaced spheres (triangles)
-    of glass, metal and paint, and six ceiling light panels of two quads each.  Smooth vertex normals everywhere (every corner carries a vn index)."""
+    of glass, metal and paint, and six ceiling light panels of two quads each.  Smooth vertex normals everywhere (every corner carries a vn index).
+    long_polygons: the flat sheets (ceiling, back and front wall) are strips that run the sheet's whole length instead of grid cells, and 96
+    thin braces (quads 3 cm wide, 3 to 9 m long) cross the hall diagonally between the columns: the long thin polygons of a modelled
+    building, whose boxes cover far more space than they do."""
     import json
     import os
     rng = np.random.default_rng(seed)
@@ -132,7 +135,12 @@ def atrium(directory, detail=1.0, seed=7):
         du, dv = np.gradient(p, axis=1), np.gradient(p, axis=0)
         # quads also where the sheet is displaced: such a cell is not planar, and the reference intersects both of its fan triangles
         # with the plane of its first three vertices (object.cpp:244), as a modelled scene's slightly warped quads are
-        faces = _grid_quads(nu, nv, False)
+        if long_polygons and bump == 0.0:
+            # one strip per column of cells: the first and the last row of the grid
+            top = (nv - 1) * nu
+            faces = np.stack([np.arange(nu - 1), np.arange(nu - 1) + 1, top + np.arange(nu - 1) + 1, top + np.arange(nu - 1)], -1)
+        else:
+            faces = _grid_quads(nu, nv, False)
         add(name, material, p.reshape(-1, 3), np.cross(du, dv).reshape(-1, 3), faces)
 
     g = max(8, int(140 * np.sqrt(detail)))
@@ -161,6 +169,15 @@ def atrium(directory, detail=1.0, seed=7):
         c = np.array([rng.uniform(-1.6, 1.6), 0.45 + 0.25 * (k % 3), -5.5 + 1.7 * k])
         v, tris = blob(sph, sph, c, 0.38 + 0.05 * (k % 2))
         add("orb.%03d" % k, mat, v, v - c, tris[:, ::-1])
+    if long_polygons:
+        # braces: thin quads between points on the two column rows, at all heights and slopes
+        ends = rng.uniform([-2.4, 0.1, -6.5], [-2.4, Y - 0.1, 6.5], (96, 3))
+        other = rng.uniform([2.4, 0.1, -6.5], [2.4, Y - 0.1, 6.5], (96, 3))
+        other[:, 2] = np.clip(ends[:, 2] + rng.uniform(-6.0, 6.0, 96), -6.5, 6.5)
+        side = np.array([0.0, 0.03, 0.0])
+        v = np.stack([ends, other, other + side, ends + side], 1).reshape(-1, 3)
+        nrm = np.cross(other - ends, side)
+        add("braces", "bronze", v, np.repeat(nrm, 4, axis=0), np.arange(4 * 96).reshape(96, 4))
     # light panels just below the ceiling, facing down: two quads each
     for k in range(6):
         cx, cz = (-1.5 if k % 2 == 0 else 1.5), -5.0 + (k // 2) * 5.0

@@ -96,7 +96,7 @@ def test_soup_closest(ctx, n, sigma):
     ctx.upload_mesh(mesh)
     ctx.set_builder(capi.BUILDER_AUTO)
     nodes, tri_index = ctx.bvh2()
-    assert sorted(tri_index.tolist()) == list(range(n))
+    assert sorted(set(tri_index.tolist())) == list(range(n))  # a triangle whose reference was cut appears once per piece
     rays = synth.incoherent_rays(100000, seed=777)
     hits, t64 = ctx.trace_closest(rays, want_t64=True)
     # the pruned, ordered walk over the product's own tree with the reference triangle test ...

@@ -13,9 +13,10 @@ ap.add_argument("--spp", type=int, default=32)
 ap.add_argument("--algorithm", default="mis")
 ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
+ap.add_argument("--long-polygons", action="store_true", help="the hall with strips and braces (synth.atrium(long_polygons=True))")
 args = ap.parse_args()
 d = tempfile.mkdtemp()
-t0 = time.time(); paths = synth.atrium(os.path.join(d, "hall")); t_synth = time.time() - t0
+t0 = time.time(); paths = synth.atrium(os.path.join(d, "hall"), long_polygons=args.long_polygons); t_synth = time.time() - t0
 r = Renderer(0, seed=5)
 t0 = time.time(); r.Load(paths["obj"]); t_load = time.time() - t0
 mats, omm = scene_io.load_materials(paths["materials"]), scene_io.load_objmatmap(paths["objmatmap"])
@@ -37,7 +38,7 @@ while s < args.spp + per:
 ctx.render_sync(); dt = time.perf_counter() - t0
 prof = ctx.profile_stop(); st2 = ctx.stats()
 k = prof["closest"]
-print(json.dumps({"scene": "hall", "polygons": paths["polygons"], "triangles": st["n_triangles"], "objects": paths["objects"], "lights": st["n_lights"],
+print(json.dumps({"scene": "hall with long polygons" if args.long_polygons else "hall", "polygons": paths["polygons"], "triangles": st["n_triangles"], "objects": paths["objects"], "lights": st["n_lights"], "cut_triangles": ctx.reference_cutting()[0], "extra_references": ctx.reference_cutting()[1],
                   "obj_load_s": t_load, "upload_and_materials_s": t_mat, "bvh_build_s": st["bvh_build_seconds"], "bvh_depth": st["bvh_depth"],
                   "width": nx, "height": ny, "algorithm": args.algorithm, "spp": args.spp, "spp_per_s": args.spp / dt,
                   "msamples_per_s": args.spp * nx * ny / dt / 1e6, "rays_per_sample": (st2["closest_rays"] + st2["any_rays"]) / max(st2["camera_samples"], 1),
