@@ -436,6 +436,80 @@ def test_polygons_that_are_not_planar_have_the_brute_force_answer(ctx, builder):
     assert (np.any((p < lo) | (p > hi), axis=1)).sum() > 0
 
 
+def long_polygon_scene(seed):
+    """small clutter with long thin triangles and long, slightly warped quads lying diagonally through it: the polygons whose
+    references the builders cut into pieces (csrc/presplit.h)"""
+    rng = np.random.default_rng(seed)
+    polys = []
+    for k in range(120):
+        a = rng.uniform(-1, 1, 3)
+        d = rng.normal(size=3)
+        d *= rng.uniform(0.5, 2.0) / np.linalg.norm(d)
+        w = np.cross(d, rng.normal(size=3))
+        w *= rng.uniform(0.002, 0.02) / np.linalg.norm(w)
+        if k % 2:
+            polys.append(np.stack([a, a + d, a + d + w]))
+        else:  # a quad whose last vertices leave the plane of the first three, some corners obtuse
+            n = np.cross(d, w)
+            n /= np.linalg.norm(n)
+            skew = rng.uniform(-0.2, 0.2) * d
+            polys.append(np.stack([a, a + d, a + d + w + skew + 10.0 ** rng.uniform(-9, -1.5) * np.linalg.norm(w) * n, a + w + skew]))
+    c = rng.uniform(-1, 1, (9000, 1, 3))
+    polys += list(c + rng.normal(size=(9000, 3, 3)) * 0.004)
+    return polygon_mesh(polys), 120
+
+
+@pytest.mark.parametrize("builder", [capi.BUILDER_HOST_SAH, capi.BUILDER_DEVICE_LBVH])
+def test_cut_references_have_the_brute_force_answer(ctx, builder):
+    """Long triangles enter the tree as several references, each with the box of a piece.  The closest hit must still be the one a loop
+    over all polygons finds (hittablelist.cpp:3-17) -- for rays aimed along and across the long polygons in particular, whose hit
+    points lie next to the planes the references were cut at -- and must not depend on whether anything was cut."""
+    mesh, n_long = long_polygon_scene(31)
+    sc = oracle.Scene(mesh)
+    rng = np.random.default_rng(8)
+    rays = synth.incoherent_rays(30000, seed=41)
+    aimed = synth.incoherent_rays(50000, seed=42)
+    tri_v = fan_triangle_vertices(mesh, rng.integers(0, n_long + n_long // 2, len(aimed)))  # the long polygons' fan triangles come first
+    u = rng.dirichlet([0.7, 0.7, 0.7], len(aimed))
+    u[::5] = np.round(u[::5])                                   # every fifth ray at a vertex
+    u[1::5, 2] = 0.0
+    u[1::5] /= u[1::5].sum(1, keepdims=True)                    # and every fifth at an edge
+    target = np.einsum("ij,ijk->ik", u, tri_v)
+    aimed[:, 4:7] = (target - aimed[:, 0:3]).astype(np.float32)
+    along = synth.incoherent_rays(20000, seed=43)               # rays that run along a long polygon, just above it
+    tv = fan_triangle_vertices(mesh, rng.integers(0, n_long + n_long // 2, len(along)))
+    along[:, 0:3] = (tv[:, 0] + 1e-3 * rng.normal(size=(len(along), 3))).astype(np.float32)
+    along[:, 4:7] = (tv[:, 1] - tv[:, 0] + 0.02 * rng.normal(size=(len(along), 3))).astype(np.float32)
+    rays = np.concatenate([rays, aimed, along])
+    o_poly, o_tri, o_t = sc.trace_closest(rays, oracle.MODE_LIST_LOWEST)
+    assert (o_poly >= 0).mean() > 0.35 and ((o_poly >= 0) & (o_poly < n_long)).mean() > 0.3
+    ctx.set_builder(builder)
+    results = []
+    for budget in (0.25, 0.0, 4.0):
+        ctx.set_reference_cutting(budget)
+        ctx.upload_mesh(mesh)
+        n_cut, n_extra = ctx.reference_cutting()
+        if budget == 0.0:
+            assert n_cut == 0 and n_extra == 0
+        else:
+            assert n_cut >= n_long // 2 and n_extra >= 4 * n_cut
+            wn, wt = ctx.wide_bvh()
+            assert len(wt) == sc.n_triangles + n_extra and set(wt.tolist()) == set(range(sc.n_triangles))
+        hits, t64 = ctx.trace_closest(rays, want_t64=True)
+        gp = hits["prim"].astype(np.int64)
+        gp[hits["prim"] == capi.MISS] = -1
+        assert np.array_equal(t64, o_t), "t differs from the loop over all polygons on %d rays" % (t64 != o_t).sum()
+        assert (gp != o_poly).sum() <= 2  # exact ties in t
+        results.append((hits.copy(), t64.copy()))
+        short = rays.copy()
+        short[:, 7] = 0.6
+        assert np.array_equal(ctx.trace_any(short), sc.trace_any(short, oracle.MODE_LIST))
+    for h, t in results[1:]:
+        assert np.array_equal(h, results[0][0]) and np.array_equal(t, results[0][1])
+    ctx.set_reference_cutting(0.25)
+    ctx.set_builder(capi.BUILDER_AUTO)
+
+
 def fan_triangle_vertices(mesh, tri):
     """[n, 3, 3] vertices of fan triangles given by their index in polygon order"""
     begin = mesh["face_begin"].astype(np.int64)
