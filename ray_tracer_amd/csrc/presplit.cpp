@@ -12,7 +12,7 @@
 namespace mi355rt {
 namespace {
 
-constexpr double kMissesPerHit = 2.0; // a piece is worth its reference while this many rays miss it per ray that hits it
+static double kMissesPerHit = 2.0; // a piece is worth its reference while this many rays miss it per ray that hits it
 constexpr int kGridBits = 21; // the spatial-median planes are those of the device builder's Morton grid (21 bits per axis)
 
 inline float round_down(double x)
@@ -230,6 +230,7 @@ void presplit(const HostScene &scene, const PresplitOptions &opt, Presplit &out)
 	// have if boxes could turn (twice its projections).  The two fan triangles of an axis-aligned rectangle waste half their
 	// boxes each, but a ray through the wasted half of one hits the other: what counts there is the waste of the polygon's box,
 	// which is nothing.  A triangle's waste is therefore the smaller of its own and its polygon's.
+	if (const char *e = std::getenv("MI355RT_CUT_RATIO")) kMissesPerHit = std::atof(e); // experiments
 	std::vector<float> waste(n), most(n); // most: the largest number of pieces that pays (below)
 	parallel_for(scene.n_faces, 1 << 14, [&](uint64_t f_begin, uint64_t f_end) {
 		for (uint64_t f = f_begin; f < f_end; f++) {
@@ -269,11 +270,25 @@ void presplit(const HostScene &scene, const PresplitOptions &opt, Presplit &out)
 	// piece saves waste / k^2: pieces are added while that is more than kWorth times what a typical triangle of the scene wastes,
 	// k = sqrt(waste / (kWorth * typical)).  "Typical" is the cube of the mean cube root: a few huge triangles do not move it.
 	// A scene whose triangles are all of a size gets no cuts at all (k < 2 up to 16 times the typical waste: four times the size).
-	double sum_cbrt = 0.0;
-	for (uint64_t t = 0; t < n; t++) sum_cbrt += std::cbrt((double)waste[t]);
+	// sums over fixed parts of the triangles, added up in order: the same result whatever the number of threads
+	auto sum_over = [&](auto term) {
+		std::vector<double> part(kParts, 0.0);
+		parallel_for(kParts, 1, [&](uint64_t p_begin, uint64_t p_end) {
+			for (uint64_t p = p_begin; p < p_end; p++) {
+				double acc = 0.0;
+				for (uint64_t t = n * p / kParts; t < n * (p + 1) / kParts; t++) acc += term(t);
+				part[p] = acc;
+			}
+		});
+		double total = 0.0;
+		for (unsigned p = 0; p < kParts; p++) total += part[p];
+		return total;
+	};
+	const double sum_cbrt = sum_over([&](uint64_t t) { return std::cbrt((double)waste[t]); });
 	const double mean_cbrt = sum_cbrt / (double)n, typical = mean_cbrt * mean_cbrt * mean_cbrt;
 	if (!(typical > 0.0)) return;
-	const double kWorth = 4.0;
+	double kWorth = 4.0;
+	if (const char *e = std::getenv("MI355RT_CUT_WORTH")) kWorth = std::atof(e); // experiments
 	auto pieces_of = [&](uint64_t t, double shrink) {
 		const double k = std::floor(std::min(std::sqrt((double)waste[t] / (kWorth * typical)), (double)most[t]) * shrink);
 		return k < 2.0 ? 1u : (uint32_t)std::min<double>(k, (double)opt.max_pieces);
@@ -282,8 +297,8 @@ void presplit(const HostScene &scene, const PresplitOptions &opt, Presplit &out)
 	const double allowed = (double)opt.budget * (double)n;
 	double shrink = 1.0;
 	for (int round = 0; round < 40; round++) {
-		double total = 0.0;
-		for (uint64_t t = 0; t < n; t++) total += (double)(pieces_of(t, shrink) - 1u);
+		const float least = (float)(4.0 * kWorth * typical / (shrink * shrink) * 0.999); // below this waste a triangle stays whole
+		const double total = sum_over([&](uint64_t t) { return waste[t] < least ? 0.0 : (double)(pieces_of(t, shrink) - 1u); });
 		if (total <= allowed) break;
 		shrink *= std::max(0.5, std::min(0.95, allowed / total));
 	}
@@ -291,7 +306,9 @@ void presplit(const HostScene &scene, const PresplitOptions &opt, Presplit &out)
 	std::vector<uint32_t> chosen, splits;
 	std::vector<uint64_t> offset;
 	uint64_t room = 0;
+	const float least = (float)(4.0 * kWorth * typical / (shrink * shrink) * 0.999);
 	for (uint64_t t = 0; t < n; t++) {
+		if (waste[t] < least) continue;
 		const uint32_t k = pieces_of(t, shrink);
 		if (k >= 2u) {
 			chosen.push_back((uint32_t)t);
