@@ -345,6 +345,7 @@ try {
 		opt.optimal_cut = triangle_record_stride(nt) == 8 ? 1 : 0;
 		if (const char *s = std::getenv("MI355RT_WIDE_CUT")) opt.optimal_cut = std::atoi(s);        // experiments
 		if (const char *s = std::getenv("MI355RT_WIDE_COST_TRI")) opt.wide_cost_tri = (float)std::atof(s);
+		if (const char *s = std::getenv("MI355RT_SLOTS")) opt.slot_assignment = std::atoi(s);
 		build_bvh(ctx->host, opt, &cut, ctx->bvh, ctx->wide);
 		ctx->built_on_device = false;
 		ctx->device_nodes = ctx->wide.nodes.size();

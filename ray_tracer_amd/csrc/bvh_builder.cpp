@@ -330,6 +330,45 @@ struct WideFlattener {
 			dist[i] = dsum;
 		}
 		std::sort(order, order + nk, [&](int x, int y) { return dist[x] > dist[y] || (dist[x] == dist[y] && x < y); });
+		if (b.opt.slot_assignment >= 1) {
+			// the assignment of children to slots that maximises the sum over the children of (centre - node centre) . (the slot's
+			// octant direction), as Ylitie, Karras and Laine choose it (HPG 2017, section 4.2), found exactly: best[mask] = the best
+			// total for the first popcount(mask) children placed in the slots of mask
+			float score[8][8];
+			for (int i = 0; i < nk; i++)
+				for (int sl = 0; sl < 8; sl++) {
+					float t = 0.0f;
+					for (int a = 0; a < 3; a++) {
+						const float c = 0.5f * (b.temp[kids[i]].box.lo[a] + b.temp[kids[i]].box.hi[a]), m = 0.5f * (box.lo[a] + box.hi[a]);
+						const float w = b.opt.slot_assignment == 2 ? 1.0f / std::max(box.hi[a] - box.lo[a], 1e-30f) : 1.0f;
+						t += (((sl >> a) & 1) ? c - m : m - c) * w;
+					}
+					score[i][sl] = t;
+				}
+			float best[256];
+			uint8_t from[256];
+			best[0] = 0.0f;
+			for (int mask = 1; mask < 256; mask++) {
+				const int i = __builtin_popcount((unsigned)mask) - 1; // the child this step places
+				best[mask] = -std::numeric_limits<float>::infinity();
+				from[mask] = 0;
+				if (i >= nk) continue;
+				for (int sl = 0; sl < 8; sl++)
+					if ((mask >> sl) & 1) {
+						const float v = best[mask ^ (1 << sl)] + score[i][sl];
+						if (v > best[mask]) { best[mask] = v; from[mask] = (uint8_t)sl; }
+					}
+			}
+			int top = -1;
+			for (int mask = 0; mask < 256; mask++)
+				if (__builtin_popcount((unsigned)mask) == nk && (top < 0 || best[mask] > best[top])) top = mask;
+			for (int mask = top, i = nk - 1; i >= 0; i--) {
+				const int sl = from[mask];
+				slot_of[i] = sl;
+				child_in_slot[sl] = i;
+				mask ^= 1 << sl;
+			}
+		} else
 		for (int oi = 0; oi < nk; oi++) {
 			const int i = order[oi];
 			int want = 0;

@@ -28,6 +28,8 @@ struct BvhBuildOptions {
 	// the collapse to 8-wide nodes: 1 = the cut of the binary tree that minimises the surface-area cost of the wide tree (dynamic
 	// programme over the number of roots a subtree is cut into), 0 = open the child with the largest area until there are eight
 	int optimal_cut = 1;
+	int slot_assignment = 1; // 1: the assignment of children to slots that maximises the sum of (centre offset) . (the slot's octant direction), 2: the same with
+	                         // offsets in units of the node's extents, 0: children take the free slot nearest their octant, far children first (1-4 % slower to trace)
 	float wide_cost_node = 1.0f; // one 8-wide node fetched and tested
 	float wide_cost_tri = 1.5f;  // one triangle record fetched and tested (swept 0.3 .. 3 on the Cornell box, the 1M soup and a 490 k-triangle
 	                             // hall: 1.5 is the best or within noise of it on all three; 0.5 costs the Cornell box 17 %)

@@ -565,36 +565,43 @@ __global__ void __launch_bounds__(kBlock) k_collapse(const BinNode *__restrict__
 		nd.e[a] = (uint8_t)(e + 127);
 		scale[a] = ldexp(1.0, e);
 	}
-	// ---- slots: the octant of the child's centre relative to the node's centre; children far from the centre choose first
+	// ---- slots: child i sits best in the slot whose octant direction its centre's offset from the node's centre points along.
+	// The assignment that maximises the sum over the children of offset . direction (Ylitie, Karras, Laine, HPG 2017, section 4.2) is
+	// found exactly: best[mask] = the best total for the first popcount(mask) children placed in the slots of mask (2048 steps).
+	// (Children taking the nearest free slot in turn, far ones first, traced 1-4 % slower.)
 	int child_in_slot[8];
 	for (int sl = 0; sl < 8; sl++) child_in_slot[sl] = -1;
-	float dist[8];
-	int want[8];
-	for (int i = 0; i < nk; i++) {
-		const float clo[3] = {kb[i].lo.x, kb[i].lo.y, kb[i].lo.z}, chi[3] = {kb[i].hi.x, kb[i].hi.y, kb[i].hi.z};
-		float dsum = 0.0f;
-		int w = 0;
-		for (int a = 0; a < 3; a++) {
-			const float c = 0.5f * (clo[a] + chi[a]), m = 0.5f * (blo[a] + bhi[a]);
-			dsum += fabsf(c - m);
-			if (c > m) w |= 1 << a;
+	{
+		float off[8][3];
+		for (int i = 0; i < nk; i++) {
+			const float clo[3] = {kb[i].lo.x, kb[i].lo.y, kb[i].lo.z}, chi[3] = {kb[i].hi.x, kb[i].hi.y, kb[i].hi.z};
+			for (int a = 0; a < 3; a++) off[i][a] = 0.5f * (clo[a] + chi[a]) - 0.5f * (blo[a] + bhi[a]);
 		}
-		dist[i] = dsum;
-		want[i] = w;
-	}
-	uint32_t placed = 0;
-	for (int round = 0; round < nk; round++) {
-		int i = -1;
-		for (int k = 0; k < nk; k++)
-			if (!((placed >> k) & 1u) && (i < 0 || dist[k] > dist[i])) i = k;
-		placed |= 1u << i;
-		int best_slot = -1, best_d = 99;
-		for (int sl = 0; sl < 8; sl++) {
-			if (child_in_slot[sl] >= 0) continue;
-			const int dd = __popc((unsigned)(sl ^ want[i]));
-			if (dd < best_d) { best_d = dd; best_slot = sl; }
+		float best[256];
+		uint8_t from[256];
+		best[0] = 0.0f;
+		for (int mask = 1; mask < 256; mask++) {
+			const int i = __popc((unsigned)mask) - 1; // the child this step places
+			float bv = -FLT_MAX;
+			int bs = 0;
+			if (i < nk)
+				for (int sl = 0; sl < 8; sl++)
+					if ((mask >> sl) & 1) {
+						const float sc = ((sl & 1) ? off[i][0] : -off[i][0]) + ((sl & 2) ? off[i][1] : -off[i][1]) + ((sl & 4) ? off[i][2] : -off[i][2]);
+						const float v = best[mask ^ (1 << sl)] + sc;
+						if (v > bv) { bv = v; bs = sl; }
+					}
+			best[mask] = bv;
+			from[mask] = (uint8_t)bs;
 		}
-		child_in_slot[best_slot] = i;
+		int top = -1;
+		for (int mask = 0; mask < 256; mask++)
+			if (__popc((unsigned)mask) == nk && (top < 0 || best[mask] > best[top])) top = mask;
+		for (int mask = top, i = nk - 1; i >= 0; i--) {
+			const int sl = from[mask];
+			child_in_slot[sl] = i;
+			mask ^= 1 << sl;
+		}
 	}
 	// ---- quantise; count interior children and leaf triangles
 	for (int a = 0; a < 3; a++)
