@@ -19,6 +19,7 @@
 #include <cfloat>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include "accept_region.h"
 #include "bvh_builder.h"
@@ -402,11 +403,60 @@ __global__ void __launch_bounds__(kBlock) k_fit_leaves(const int32_t *__restrict
 	}
 }
 
-__global__ void __launch_bounds__(kBlock) k_fit_round(const BinNode *__restrict__ nodes, const int32_t *__restrict__ parent_of_node,
+// Settles one node of the binary tree whose children (links `left`, `right`) are settled: its box, and the cut into 8-wide nodes that
+// minimises the surface-area cost of the wide tree, as in the host builder (bvh_builder.cpp, WideCut): cost[i - 1] is the cheapest way
+// to represent the subtree by at most i roots, each a leaf child of at most kMaxLeaf triangles or an 8-wide node; cut[i - 1] = 0 means
+// "as for i - 1" (a leaf when i = 1), k > 0 that the left subtree supplies k of the roots (of the eight children when i = 1).
+// count: references under the node when they are a run of the sorted order (only a run can become a leaf child), else 0.
+__device__ __forceinline__ Box4 fit_node(int node, int32_t left, int32_t right, uint32_t count, const Box4 *node_boxes, const float *node_cost,
+                                         const Box4 *__restrict__ tri_boxes, const uint32_t *__restrict__ sorted_tri, Box4 *node_boxes_out, float *node_cost_out,
+                                         uint8_t *node_cut, uint8_t *__restrict__ as_leaf)
+{
+	const Box4 a = left >= 0 ? node_boxes[left] : tri_boxes[sorted_tri[~left]];
+	const Box4 b = right >= 0 ? node_boxes[right] : tri_boxes[sorted_tri[~right]];
+	float cl[7], cr[7];
+	for (int i = 0; i < 7; i++) {
+		cl[i] = left >= 0 ? node_cost[7 * (size_t)left + i] : kCostTri * half_area(a);
+		cr[i] = right >= 0 ? node_cost[7 * (size_t)right + i] : kCostTri * half_area(b);
+	}
+	const Box4 u = box_union(a, b);
+	const float whole = count != 0u && count <= kMaxLeaf ? kCostTri * (float)count * half_area(u) : FLT_MAX;
+	float best = FLT_MAX;
+	int bk = 1;
+	for (int k = 1; k <= 7; k++) {
+		const float v = cl[k - 1] + cr[7 - k];
+		if (v < best) { best = v; bk = k; }
+	}
+	const float split = kCostNode * half_area(u) + best;
+	const bool leaf_wins = whole <= split;
+	float c[7];
+	uint8_t d[7];
+	c[0] = leaf_wins ? whole : split;
+	d[0] = leaf_wins ? 0 : (uint8_t)bk;
+	for (int i = 2; i <= 7; i++) {
+		float v = c[i - 2];
+		int dk = 0;
+		for (int k = 1; k < i; k++) {
+			const float w = cl[k - 1] + cr[i - k - 1];
+			if (w < v) { v = w; dk = k; }
+		}
+		c[i - 1] = v;
+		d[i - 1] = (uint8_t)dk;
+	}
+	node_boxes_out[node] = u;
+	for (int i = 0; i < 7; i++) { node_cost_out[7 * (size_t)node + i] = c[i]; node_cut[7 * (size_t)node + i] = d[i]; }
+	as_leaf[node] = leaf_wins ? 1 : 0;
+	return u;
+}
+
+// A node whose references are no run of the sorted order any more (after a rotation below) says so with this `last`.
+constexpr uint32_t kNoRun = 0x7FFFFFFFu;
+
+__global__ void __launch_bounds__(kBlock) k_fit_round(BinNode *nodes, const int32_t *__restrict__ parent_of_node,
                                                       const Box4 *__restrict__ tri_boxes, const uint32_t *__restrict__ sorted_tri,
                                                       const uint32_t *__restrict__ ready_in, unsigned int n_in, Box4 *node_boxes, float *node_cost,
                                                       uint8_t *node_cut, uint8_t *__restrict__ as_leaf, unsigned int *__restrict__ arrived,
-                                                      uint32_t *__restrict__ ready_out, unsigned int *__restrict__ tail)
+                                                      uint32_t *__restrict__ ready_out, unsigned int *__restrict__ tail, int rotate)
 {
 	const unsigned int rounds = (n_in + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
 	for (unsigned int r = 0; r < rounds; r++) {
@@ -415,46 +465,61 @@ __global__ void __launch_bounds__(kBlock) k_fit_round(const BinNode *__restrict_
 		int up = 0;
 		if (qi < n_in) {
 			const int node = (int)ready_in[qi];
-			const BinNode nd = nodes[node];
-			const Box4 a = nd.left >= 0 ? node_boxes[nd.left] : tri_boxes[sorted_tri[~nd.left]];
-			const Box4 b = nd.right >= 0 ? node_boxes[nd.right] : tri_boxes[sorted_tri[~nd.right]];
-			// The cut into 8-wide nodes that minimises the surface-area cost of the wide tree, as in the host builder (bvh_builder.cpp,
-			// WideCut): cost[i - 1] is the cheapest way to represent the subtree by at most i roots, each a leaf child of at most
-			// kMaxLeaf triangles or an 8-wide node; cut[i - 1] = 0 means "as for i - 1" (a leaf when i = 1), k > 0 that the left
-			// subtree supplies k of the roots (of the eight children when i = 1).
-			float cl[7], cr[7];
-			for (int i = 0; i < 7; i++) {
-				cl[i] = nd.left >= 0 ? node_cost[7 * (size_t)nd.left + i] : kCostTri * half_area(a);
-				cr[i] = nd.right >= 0 ? node_cost[7 * (size_t)nd.right + i] : kCostTri * half_area(b);
-			}
-			const Box4 u = box_union(a, b);
-			const uint32_t count = nd.last - nd.first + 1u;
-			const float whole = count <= kMaxLeaf ? kCostTri * (float)count * half_area(u) : FLT_MAX;
-			float best = FLT_MAX;
-			int bk = 1;
-			for (int k = 1; k <= 7; k++) {
-				const float v = cl[k - 1] + cr[7 - k];
-				if (v < best) { best = v; bk = k; }
-			}
-			const float split = kCostNode * half_area(u) + best;
-			const bool leaf_wins = whole <= split;
-			float c[7];
-			uint8_t d[7];
-			c[0] = leaf_wins ? whole : split;
-			d[0] = leaf_wins ? 0 : (uint8_t)bk;
-			for (int i = 2; i <= 7; i++) {
-				float v = c[i - 2];
-				int dk = 0;
-				for (int k = 1; k < i; k++) {
-					const float w = cl[k - 1] + cr[i - k - 1];
-					if (w < v) { v = w; dk = k; }
+			BinNode nd = nodes[node];
+			auto box_of = [&](int32_t link) { return link >= 0 ? node_boxes[link] : tri_boxes[sorted_tri[~link]]; };
+			auto first_of = [&](int32_t link) { return link >= 0 ? nodes[link].first : (uint32_t)~link; };
+			auto last_of = [&](int32_t link) { return link >= 0 ? nodes[link].last : (uint32_t)~link; };
+			// ---- a rotation (Kensler, "Tree Rotations for Improving Bounding Volume Hierarchies", 2008): a child of this node changes
+			// places with a grandchild on the other side when that makes the box of the node in between smaller.  The Morton tree
+			// splits space in the middle whatever lies there; this is the one local repair that fits into the bottom-up pass: both
+			// children and all four grandchildren are settled, nobody else reads or writes them, and the node that is rebuilt (the
+			// child that keeps its index and gets the other pair) is settled again right here.  Two of the four exchanges leave the
+			// rebuilt node with references that are no run of the sorted order; such a node cannot become a leaf child (kNoRun).
+			for (int turn = 0; turn < rotate; turn++) {
+				const int32_t L = nd.left, R = nd.right;
+				float gain = 0.0f;
+				int which = 0;
+				if (R >= 0) {
+					const BinNode rn = nodes[R];
+					const float now = half_area(node_boxes[R]);
+					const Box4 lb = box_of(L);
+					const float g1 = now - half_area(box_union(lb, box_of(rn.right))); // L <-> R.left:  R = (L, R.right)
+					const float g2 = now - half_area(box_union(lb, box_of(rn.left)));  // L <-> R.right: R = (L, R.left)
+					if (g1 > gain) { gain = g1; which = 1; }
+					if (g2 > gain) { gain = g2; which = 2; }
 				}
-				c[i - 1] = v;
-				d[i - 1] = (uint8_t)dk;
+				if (L >= 0) {
+					const BinNode ln = nodes[L];
+					const float now = half_area(node_boxes[L]);
+					const Box4 rb = box_of(R);
+					const float g3 = now - half_area(box_union(box_of(ln.right), rb)); // R <-> L.left:  L = (L.right, R)
+					const float g4 = now - half_area(box_union(box_of(ln.left), rb));  // R <-> L.right: L = (L.left, R)
+					if (g3 > gain) { gain = g3; which = 3; }
+					if (g4 > gain) { gain = g4; which = 4; }
+				}
+				if (which != 0) {
+					const int32_t mid = which <= 2 ? R : L; // the node that is rebuilt
+					BinNode mn = nodes[mid];
+					int32_t out_link, in_link = which <= 2 ? L : R; // leaves mid, enters mid
+					if (which == 1) { out_link = mn.left; mn.left = in_link; }
+					else if (which == 2) { out_link = mn.right; mn.right = mn.left; mn.left = in_link; }      // (L, R.left): in sorted order
+					else if (which == 3) { out_link = mn.left; mn.left = mn.right; mn.right = in_link; }       // (L.right, R): in sorted order
+					else { out_link = mn.right; mn.right = in_link; }
+					// a run of the sorted order only if both parts are runs and the second starts where the first ends
+					const uint32_t f0 = first_of(mn.left), l0 = last_of(mn.left), f1 = first_of(mn.right), l1 = last_of(mn.right);
+					const bool run = l0 != kNoRun && l1 != kNoRun && l0 + 1u == f1;
+					mn.first = run ? f0 : 0u;
+					mn.last = run ? l1 : kNoRun;
+					nodes[mid] = mn;
+					fit_node(mid, mn.left, mn.right, run ? l1 - f0 + 1u : 0u, node_boxes, node_cost, tri_boxes, sorted_tri, node_boxes, node_cost, node_cut, as_leaf);
+					if (which <= 2) { nd.left = out_link; nd.right = mid; }
+					else { nd.left = mid; nd.right = out_link; }
+					// this node's own references are the same set as before: its run stands
+					nodes[node] = nd;
+				} else break;
 			}
-			node_boxes[node] = u;
-			for (int i = 0; i < 7; i++) { node_cost[7 * (size_t)node + i] = c[i]; node_cut[7 * (size_t)node + i] = d[i]; }
-			as_leaf[node] = leaf_wins ? 1 : 0;
+			const uint32_t count = nd.last != kNoRun ? nd.last - nd.first + 1u : 0u;
+			fit_node(node, nd.left, nd.right, count, node_boxes, node_cost, tri_boxes, sorted_tri, node_boxes, node_cost, node_cut, as_leaf);
 			up = parent_of_node[node];
 			if (up >= 0) second = atomicAdd(&arrived[up], 1u) == 1u; // the other child was settled in an earlier launch, or is settled in this one by whoever came first
 		}
@@ -787,6 +852,8 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 		// the ready lists live in the collapse queues, which are not in use yet; ctr->queue_out is the tail of the list being written
 		uint32_t *ready[2] = {reinterpret_cast<uint32_t *>(queue[0]), reinterpret_cast<uint32_t *>(queue[1])};
 		DB_TRY(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
+		int rotate = 1;
+		if (const char *e = std::getenv("MI355RT_ROTATE")) rotate = std::atoi(e); // experiments
 		hipLaunchKernelGGL(k_fit_leaves, dim3(std::min(blocks_n, kStrideBlocks)), dim3(kBlock), 0, stream, parent_of_leaf, (int)n, arrived, ready[0], &ctr->queue_out);
 		int cur = 0;
 		uint32_t settled = 0;
@@ -800,7 +867,7 @@ hipError_t build_bvh_device(const double *d_tri_a_fan, const double *d_tri_b_fan
 			DB_TRY(hipMemsetAsync(&ctr->queue_out, 0, sizeof(unsigned int), stream));
 			const unsigned blocks_r = std::min((n_ready + kBlock - 1) / kBlock, kStrideBlocks);
 			hipLaunchKernelGGL(k_fit_round, dim3(blocks_r), dim3(kBlock), 0, stream, bin, parent_of_node, tri_boxes, sorted_tri, ready[cur], n_ready, node_boxes,
-			                   node_cost, node_cut, as_leaf, arrived, ready[cur ^ 1], &ctr->queue_out);
+			                   node_cost, node_cut, as_leaf, arrived, ready[cur ^ 1], &ctr->queue_out, rotate);
 			cur ^= 1;
 		}
 		DB_TRY(hipGetLastError());
