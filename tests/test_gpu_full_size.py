@@ -244,3 +244,42 @@ def test_large_obj_project_4k(tmp_path):
     hits_dev, t_dev = ctx.trace_closest(rays, want_t64=True)
     assert np.array_equal(t_host, t_dev) and (hits_host["prim"] != hits_dev["prim"]).sum() <= 2
     ctx.close()
+
+
+def test_hall_with_long_polygons_renders_the_same_whole_or_cut(tmp_path):
+    """The hall as a modelled building has it -- strip walls and 96 thin braces crossing it diagonally (synth.atrium(long_polygons=True))
+    -- rendered with the references of its long triangles whole and cut into pieces (csrc/presplit.h), under both builders: the
+    same ray counts and the same film (the hits are the same, so the paths are; the film differs by the order of its fp32 additions)."""
+    from ray_tracer_amd import scene_io
+    from ray_tracer_amd.renderer import Renderer
+    paths = synth.atrium(str(tmp_path / "hall"), long_polygons=True)
+    mats, omm = scene_io.load_materials(paths["materials"]), scene_io.load_objmatmap(paths["objmatmap"])
+    nx, ny, ns = 480, 270, 4
+    films, rays = [], []
+    for builder in (capi.BUILDER_DEVICE_LBVH, capi.BUILDER_HOST_SAH):
+        for budget in (0.0, 0.25):
+            r = Renderer(0, seed=5)
+            r.ctx.set_builder(builder)
+            r.ctx.set_reference_cutting(budget)
+            r.Load(paths["obj"])
+            assert r.LoadMaterials({name: mats[omm[name]] for name in omm})
+            n_cut, n_extra = r.ctx.reference_cutting()
+            assert (n_cut, n_extra) == (0, 0) if budget == 0.0 else (n_cut >= 150 and n_extra >= 20 * n_cut)
+            r.cam.film_height = 0.024
+            r.cam.film_width = 0.024 * nx / ny
+            r.cam.aperture = 0.05
+            r.cam.SetLens(60.0, 0.4)
+            r.cam.set_Camera([0.0, 1.3, 7.5], [0.0, 1.1, 0.0], [0, 1, 0])
+            ctx = r.ctx
+            ctx.set_camera(r.cam)
+            ctx.render_begin(nx, ny, ns, 30, capi.ALG_MIS, 77)
+            ctx.render_pass(0, ns)
+            ctx.render_sync()
+            films.append(ctx.download_film())
+            st = ctx.stats()
+            rays.append((st["closest_rays"], st["any_rays"], st["camera_samples"]))
+            ctx.close()
+    assert films[0].sum() > 0 and np.isfinite(films[0]).all()
+    for f, n in zip(films[1:], rays[1:]):
+        assert n == rays[0]
+        assert np.allclose(f, films[0], rtol=1e-4, atol=1e-8)
