@@ -129,10 +129,11 @@ void Renderer::RenderImage(int nx, int ny, int ns, int spectral_samples, bool, b
 	int s = 0;
 	while (s < ns) {
 		if (stop_rendering) break; // once per pass, renderer.cpp:70
-		// samples_per_pass = 0: the library's choice.  Unwatched, a pass is one full device batch (2^27 paths: tens of milliseconds,
+		// samples_per_pass = 0: the library's choice.  Unwatched, a pass is one full device batch (2^28 paths where the GPU's memory allows, the
+		// library halves it where not: tens of milliseconds,
 		// so stop_rendering is still looked at many times a second).  With a preview or progress output wanted the reference serves
 		// them once per sample (renderer.cpp:69-151); here a watched render reports at least a hundred times.
-		const long long fill = std::max(1LL, (1LL << 27) / std::max(1LL, (long long)nx * ny));
+		const long long fill = std::max(1LL, (1LL << 28) / std::max(1LL, (long long)nx * ny));
 		const long long want = samples_per_pass > 0 ? samples_per_pass
 		                       : (preview_img_flag || print_progress) ? std::max(1LL, std::min<long long>(fill, ns / 100)) : fill;
 		int b = (int)std::min<long long>(want, ns - s);

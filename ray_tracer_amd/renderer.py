@@ -91,10 +91,10 @@ class Renderer:
         while s < ns:
             if self.stop_rendering:  # checked once per pass, renderer.cpp:70
                 break
-            # samples_per_pass = 0: the library's choice.  Unwatched, a pass is one full device batch (2^27 paths: tens of
-            # milliseconds, so stop_rendering is still looked at many times a second).  With a preview or progress output wanted the
+            # samples_per_pass = 0: the library's choice.  Unwatched, a pass is one full device batch (2^28 paths where the
+            # GPU's memory allows, the library halves it where not: tens of milliseconds, so stop_rendering is still looked at many times a second).  With a preview or progress output wanted the
             # reference serves them once per sample (renderer.cpp:69-151); here a watched render reports at least a hundred times.
-            fill = max(1, (1 << 27) // max(1, nx * ny))
+            fill = max(1, (1 << 28) // max(1, nx * ny))
             if self.samples_per_pass > 0:
                 want = self.samples_per_pass
             elif self.preview_img_flag or print_progress:

@@ -19,9 +19,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--material", default="glass")
-    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--spp", type=int, default=128)
     ap.add_argument("--grid", type=int, default=660)
-    ap.add_argument("--pass-spp", type=int, default=64, help="samples per pixel per render pass (one batch of the wavefront queues at 1080p)")
+    ap.add_argument("--pass-spp", type=int, default=128, help="samples per pixel per render pass (one batch of the wavefront queues at 1080p)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-oracle", action="store_true")

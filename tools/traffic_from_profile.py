@@ -26,7 +26,17 @@ from collections import defaultdict
 tag_dir, out_path = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: defaultdict(float))
 rows = defaultdict(lambda: defaultdict(int))
-for f in glob.glob(os.path.join(tag_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+def newest_per_directory(paths):
+    """one file per directory, the newest: results of an earlier run of the same passes may still lie beside the new ones"""
+    best = {}
+    for f in paths:
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
+for f in newest_per_directory(glob.glob(os.path.join(tag_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
                                  "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD",
@@ -36,7 +46,7 @@ for f in glob.glob(os.path.join(tag_dir, "pmc_*", "**", "*counter_collection.csv
             rows[k][r["Counter_Name"]] += 1
 # the kernels' own durations, from the kernel trace of the same script
 dur = defaultdict(lambda: [0.0, 0])
-for f in glob.glob(os.path.join(tag_dir, "trace", "**", "*kernel_trace.csv"), recursive=True):
+for f in newest_per_directory(glob.glob(os.path.join(tag_dir, "trace", "**", "*kernel_trace.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("mi355rt::", "").split("(")[0]
         dur[k][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
