@@ -25,6 +25,21 @@ for it in range(iters):
     builder = [capi.BUILDER_HOST_SAH, capi.BUILDER_DEVICE_LBVH][int(rng.integers(0, 2))]
     watertight = bool(rng.integers(0, 2))
     mesh = synth.soup(n, sigma, seed=int(rng.integers(1, 1 << 30)))
+    stretched = 0
+    if n >= 4096 and rng.integers(0, 2):
+        # some triangles drawn out into long thin ones (30 to 300 times along a random direction): the builders cut their references
+        # into pieces (csrc/presplit.h), with a small or a very large budget
+        stretched = int(max(1, n * 10 ** rng.uniform(-3.5, -2)))
+        pick = rng.choice(n, stretched, replace=False)
+        v = mesh["v"].reshape(n, 3, 3)
+        c = v[pick].mean(1, keepdims=True)
+        d = rng.normal(size=(stretched, 1, 3))
+        d /= np.linalg.norm(d, axis=2, keepdims=True)
+        rel = v[pick] - c
+        v[pick] = c + rel + (rel * d).sum(2, keepdims=True) * d * (10 ** rng.uniform(1.5, 2.5, (stretched, 1, 1)) - 1.0)
+        nrm = np.cross(v[pick, 1] - v[pick, 0], v[pick, 2] - v[pick, 1])
+        mesh["vn"][pick] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+        ctx.set_reference_cutting(float(rng.choice([0.25, 4.0])))
     ctx.set_builder(builder)
     ctx.set_triangle_test(capi.TRIANGLE_WATERTIGHT if watertight else capi.TRIANGLE_REFERENCE)
     ctx.upload_mesh(mesh)
@@ -48,9 +63,10 @@ for it in range(iters):
     same_list = np.array_equal(lh, hit_g[:3000]) and np.array_equal(t64[:3000][lh], l_t[lh])
     if not (same and same_list):
         bad += 1
-        print("MISMATCH it %d: n %d sigma %.4g builder %d watertight %d (tree walk %s, list %s)" % (it, n, sigma, builder, watertight, same, same_list), flush=True)
+        print("MISMATCH it %d: n %d sigma %.4g builder %d watertight %d stretched %d (tree walk %s, list %s)" % (it, n, sigma, builder, watertight, stretched, same, same_list), flush=True)
+    cut_total = globals().get("cut_total", 0) + ctx.reference_cutting()[1]
     if it % 5 == 4:
         print("%d iterations, %d mismatches, %.0f s" % (it + 1, bad, time.time() - t0), flush=True)
 ctx.close()
-print("done: %d iterations, %d mismatches" % (iters, bad))
+print("done: %d iterations, %d mismatches, %d references added by cutting in all" % (iters, bad, globals().get("cut_total", 0)))
 sys.exit(1 if bad else 0)
