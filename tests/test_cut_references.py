@@ -12,8 +12,10 @@ def mesh_of(polygons):
     """polygons: list of [k, 3] vertex arrays -> one object of them"""
     v = np.concatenate(polygons)
     starts = np.cumsum([0] + [len(p) for p in polygons])
-    vn = np.stack([np.cross(p[1] - p[0], p[2] - p[1]) for p in polygons])
-    vn /= np.linalg.norm(vn, axis=1, keepdims=True)
+    with np.errstate(invalid="ignore", over="ignore"):
+        vn = np.stack([np.cross(p[1] - p[0], p[2] - p[1]) for p in polygons])
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        vn /= np.linalg.norm(vn, axis=1, keepdims=True)
     face_of = np.repeat(np.arange(len(polygons)), [len(p) for p in polygons])
     corners = np.stack([np.arange(len(v)), np.full(len(v), -1), face_of], -1).astype(np.int64)
     return {"v": v, "vt": np.zeros((0, 3)), "vn": vn, "corners": corners,
@@ -139,3 +141,27 @@ def test_small_and_uniform_scenes_are_left_alone():
     assert len(extra) < 200
     first, extra = capi.cut_references(mesh_of(small_clutter(rng, 20000, 1.0)), budget=0.0)
     assert len(first) == 0 and len(extra) == 0
+
+
+def test_pathological_triangles_do_not_upset_the_cutting():
+    """degenerate, enormous, tiny and not-finite triangles among ordinary ones: the call returns, pieces are finite boxes inside the
+    scene's extent, and triangles that are not finite are left whole"""
+    rng = np.random.default_rng(8)
+    polys = small_clutter(rng, 5000, 1.0)
+    odd = [np.zeros((3, 3)),                                                      # a point
+           np.array([[0.0, 0, 0], [1, 1, 1], [2, 2, 2]]),                         # collinear
+           np.array([[0.0, 0, 0], [1e30, 0, 0], [0, 1e30, 0]]),                   # enormous
+           np.array([[0.0, 0, 0], [1e-30, 0, 0], [0, 1e-30, 0]]),                 # tiny
+           np.array([[np.nan, 0, 0], [1.0, 0, 0], [0, 1.0, 0]]),                  # not a number
+           np.array([[np.inf, 0, 0], [1.0, 0, 0], [0, 1.0, 0]]),                  # infinite
+           np.array([[-50.0, -50, -50], [50, 50, 50], [50, 50.001, 50]]),         # a needle through the whole scene
+           np.array([[-1.0, 0.2, 0.3], [1.0, 0.2, 0.3], [1.0, 0.2000001, 0.3]])]  # a needle along an axis
+    mesh = mesh_of(odd + polys)
+    mesh["vn"] = np.nan_to_num(mesh["vn"], nan=0.0, posinf=0.0, neginf=0.0)
+    mesh["vn"][np.linalg.norm(mesh["vn"], axis=1) == 0] = [0.0, 0.0, 1.0]
+    for budget in (0.25, 4.0):
+        first, extra = capi.cut_references(mesh, budget=budget, min_tris=1000)
+        both = np.concatenate([first, extra])
+        assert np.isfinite(both["lo"]).all() and np.isfinite(both["hi"]).all() and np.all(both["lo"] <= both["hi"])
+        assert not np.isin(both["tri"], [0, 1, 4, 5]).any()  # nothing to cut, or not finite
+        assert len(extra) <= budget * len(mesh["face_begin"])
