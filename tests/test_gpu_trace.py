@@ -510,6 +510,41 @@ def test_cut_references_have_the_brute_force_answer(ctx, builder):
     ctx.set_builder(capi.BUILDER_AUTO)
 
 
+@pytest.mark.parametrize("builder", [capi.BUILDER_HOST_SAH, capi.BUILDER_DEVICE_LBVH])
+def test_odd_triangles_among_ordinary_ones(ctx, builder):
+    """a point, a collinear triple, a triangle a million times the scene's size, one a millionth of a millionth of it, and needles
+    through the whole scene, among 6000 ordinary triangles: the builders (which cut the long ones into pieces) and the kernel give
+    the answers of the loop over all polygons"""
+    rng = np.random.default_rng(12)
+    c = rng.uniform(-1, 1, (6000, 1, 3))
+    polys = list(c + rng.normal(size=(6000, 3, 3)) * 0.01)
+    polys += [np.full((3, 3), 0.25),
+              np.array([[0.0, 0, 0], [0.1, 0.1, 0.1], [0.2, 0.2, 0.2]]),
+              np.array([[-1e6, -1e6, -0.5], [2e6, -1e6, -0.5], [-1e6, 2e6, -0.5]]),
+              np.array([[0.5, 0.5, 0.5], [0.5 + 1e-12, 0.5, 0.5], [0.5, 0.5 + 1e-12, 0.5]]),
+              np.array([[-50.0, -50, -50], [50, 50, 50], [50, 50.001, 50]]),
+              np.array([[-1.0, 0.2, 0.3], [1.0, 0.2, 0.3], [1.0, 0.2000001, 0.3]])]
+    with np.errstate(invalid="ignore"):
+        mesh = polygon_mesh(polys)
+    mesh["vn"] = np.nan_to_num(mesh["vn"])
+    mesh["vn"][np.linalg.norm(mesh["vn"], axis=1) == 0] = [0.0, 0.0, 1.0]
+    sc = oracle.Scene(mesh)
+    rays = synth.incoherent_rays(40000, seed=51)
+    aimed = synth.incoherent_rays(10000, seed=52)
+    aimed[:, 4:7] = (rng.uniform(-1, 1, (10000, 1)) * np.array([[1.0, 1.0, 1.0]]) + rng.normal(size=(10000, 3)) * 1e-3 - aimed[:, 0:3]).astype(np.float32)  # at the long needle
+    rays = np.concatenate([rays, aimed])
+    o_poly, o_tri, o_t = sc.trace_closest(rays, oracle.MODE_LIST_LOWEST)
+    assert (o_poly >= 0).mean() > 0.3 and (o_poly >= 6000).sum() > 100
+    ctx.set_builder(builder)
+    ctx.upload_mesh(mesh)
+    ctx.set_builder(capi.BUILDER_AUTO)
+    assert ctx.reference_cutting()[0] >= 1  # the diagonal needle (the axis-aligned one and the flat giant waste nothing)
+    hits, t64 = ctx.trace_closest(rays, want_t64=True)
+    gp = hits["prim"].astype(np.int64)
+    gp[hits["prim"] == capi.MISS] = -1
+    assert np.array_equal(t64, o_t) and (gp != o_poly).sum() <= 2
+
+
 def fan_triangle_vertices(mesh, tri):
     """[n, 3, 3] vertices of fan triangles given by their index in polygon order"""
     begin = mesh["face_begin"].astype(np.int64)
