@@ -12,7 +12,7 @@
 namespace mi355rt {
 namespace {
 
-static double kMissesPerHit = 2.0; // a piece is worth its reference while this many rays miss it per ray that hits it
+constexpr double kMissesPerHit = 2.0; // a piece is worth its reference while this many rays miss it per ray that hits it
 constexpr int kGridBits = 21; // the spatial-median planes are those of the device builder's Morton grid (21 bits per axis)
 
 inline float round_down(double x)
@@ -230,7 +230,8 @@ void presplit(const HostScene &scene, const PresplitOptions &opt, Presplit &out)
 	// have if boxes could turn (twice its projections).  The two fan triangles of an axis-aligned rectangle waste half their
 	// boxes each, but a ray through the wasted half of one hits the other: what counts there is the waste of the polygon's box,
 	// which is nothing.  A triangle's waste is therefore the smaller of its own and its polygon's.
-	if (const char *e = std::getenv("MI355RT_CUT_RATIO")) kMissesPerHit = std::atof(e); // experiments
+	double misses_per_hit = kMissesPerHit;
+	if (const char *e = std::getenv("MI355RT_CUT_RATIO")) misses_per_hit = std::atof(e); // experiments
 	std::vector<float> waste(n), most(n); // most: the largest number of pieces that pays (below)
 	parallel_for(scene.n_faces, 1 << 14, [&](uint64_t f_begin, uint64_t f_end) {
 		for (uint64_t f = f_begin; f < f_end; f++) {
@@ -253,7 +254,7 @@ void presplit(const HostScene &scene, const PresplitOptions &opt, Presplit &out)
 				const double w = 2.0 * (dx * dy + dy * dz + dz * dx) - ideal;
 				p_ideal += ideal;
 				waste[t] = w > 0.0 && w < 1e300 ? (float)w : 0.0f;
-				most[t] = ideal > 0.0 ? (float)std::min(1e9, w / (kMissesPerHit * ideal)) : 1e9f;
+				most[t] = !(w > 0.0) ? 0.0f : (ideal > 0.0 ? (float)std::min(1e9, w / (misses_per_hit * ideal)) : 1e9f);
 			}
 			const double dx = phi[0] - plo[0], dy = phi[1] - plo[1], dz = phi[2] - plo[2];
 			const double pw = 2.0 * (dx * dy + dy * dz + dz * dx) - p_ideal;
