@@ -1931,7 +1931,7 @@ static hipError_t ensure_bdpt(Impl &im, uint64_t cap, hipStream_t stream, std::s
 	HIP_TRY(hipMalloc(&im.bdpt_verts, cap * 2 * kBdptMax * sizeof(BdptVertex)));
 	HIP_TRY(hipMalloc((void **)&im.bdpt_counts, cap * sizeof(uint32_t)));
 	HIP_TRY(hipMalloc((void **)&im.bdpt_offsets, cap * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void **)&im.bdpt_pairs, sizeof(unsigned long long)));
+	HIP_TRY(hipMalloc((void **)&im.bdpt_pairs, 2 * sizeof(unsigned long long))); // the batch's vertex pairs, and (second word) the tail of its connection queue
 	im.bdpt_scan_bytes = sizeof(uint32_t) * ((cap + kScanTile - 1) / kScanTile); // one sum per tile of the slot-count scan
 	HIP_TRY(hipMalloc(&im.bdpt_scan_tmp, std::max<size_t>(im.bdpt_scan_bytes, 1)));
 	im.bdpt_capacity = cap;
@@ -2046,10 +2046,13 @@ static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &ge
 	HIP_TRY(hipStreamSynchronize(stream));
 	settle(0, eye_rec);
 	settle(kBdptMax + 2, light_rec);
-	const uint64_t total = (uint64_t)last_off + (last_cnt & 0xFFFFu);
-	if (total >= (1ull << 32)) { err = "NaiveBDPT: more than 2^32 connections in one batch"; return hipErrorInvalidValue; }
-	if (total > im.conn_capacity) { // about 4.6 slots per sample on the Cornell box; grown on demand, kept for later batches
-		const uint64_t want = total + total / 4;
+	const uint64_t total = (uint64_t)last_off + (last_cnt & 0xFFFFu); // connections of the batch, those with a zero term included
+	// the waves of k_bdpt_connect_gen, and the slots they may need: every item if none had a zero term, and a chunk per wave
+	const unsigned gen_blocks = std::min(blocks_n, 1024u);
+	const uint64_t conn_bound = total + (uint64_t)gen_blocks * (kBlock / 64) * kBdptChunk;
+	if (conn_bound >= (1ull << 32)) { err = "NaiveBDPT: more than 2^32 connections in one batch"; return hipErrorInvalidValue; }
+	if (conn_bound > im.conn_capacity) { // about 4.6 slots per sample on the Cornell box; grown on demand, kept for later batches
+		const uint64_t want = conn_bound + total / 4;
 		if (im.conn_rays) (void)hipFree(im.conn_rays);
 		if (im.conn) (void)hipFree(im.conn);
 		if (im.conn_hits) (void)hipFree(im.conn_hits);
@@ -2072,18 +2075,29 @@ static hipError_t run_batch_bdpt(RenderState &rs, Impl &im, const DeviceGeom &ge
 		im.conn_capacity = want;
 	}
 	if (total == 0) return hipSuccess;
+	uint32_t *conn_n = reinterpret_cast<uint32_t *>(im.bdpt_pairs + 1); // the queue's tail: the slots the waves took, at most conn_bound
+	HIP_TRY(hipMemsetAsync(conn_n, 0, sizeof(uint32_t), stream));
 	prof.begin(Profiler::SHADE, n_paths, stream);
-	hipLaunchKernelGGL(k_bdpt_connect_gen, dim3(blocks_n), dim3(kBlock), 0, stream, sh, n, samples, verts, im.bdpt_offsets, im.conn_rays, im.conn);
+	hipLaunchKernelGGL(k_bdpt_connect_gen, dim3(gen_blocks), dim3(kBlock), 0, stream, sh, n, samples, verts, conn_n, im.conn_rays, im.conn);
 	prof.end(stream);
 	HIP_TRY(hipGetLastError());
 	prof.begin(Profiler::CLOSEST, total, stream);
-	HIP_TRY(launch_trace_closest(geom, im.conn_rays, total, im.conn_hits, nullptr, stream, nullptr));
+	HIP_TRY(launch_trace_closest(geom, im.conn_rays, conn_bound, im.conn_hits, nullptr, stream, conn_n));
 	prof.end(stream);
+	const long rec_trace = prof.last();
 	prof.begin(Profiler::CONNECT, total, stream);
-	hipLaunchKernelGGL(k_bdpt_connect_eval, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sh, (uint32_t)total, im.conn_rays,
+	hipLaunchKernelGGL(k_bdpt_connect_eval, dim3(stream_grid(conn_bound, kBlock)), dim3(kBlock), 0, stream, sh, conn_n, im.conn_rays,
 	                   im.conn, im.conn_hits, rs.d_film);
 	prof.end(stream);
+	const long rec_eval = prof.last();
 	HIP_TRY(hipGetLastError());
+	if (prof.enabled) { // the profile counts the slots that were traced
+		uint32_t traced = 0;
+		HIP_TRY(hipMemcpyAsync(&traced, conn_n, sizeof(traced), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		prof.set_items(rec_trace, traced);
+		prof.set_items(rec_eval, traced);
+	}
 	rs.closest_rays += total - pairs; // slots whose term was zero are counted although their ray is answered at once
 	rs.any_rays += pairs;
 	return hipSuccess;
