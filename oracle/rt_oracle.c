@@ -1778,6 +1778,9 @@ static double mis_path_tracing(const orc_scene *s, v3 o, v3 d, const band *b, ui
 /* NaiveBDPT (renderer.cpp:478-771), statement order kept.  Subpaths are std::vectors in the reference; here they are capped at
  * ORC_BDPT_MAX vertices each (survival beyond vertex k has probability 0.25 * 0.1^(k-2): 2.5e-7 at 8), the same cap the device uses. */
 #define ORC_BDPT_MAX 8
+/* debugging aid: with ORC_TRACE_PIXEL set, orc_render writes the vertices and terms of that pixel's NaiveBDPT samples to stderr */
+static __thread int trace_on = 0;
+#define TR(...) do { if (trace_on) fprintf(stderr, __VA_ARGS__); } while (0)
 static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t *rng, orc_render_stats *st)
 {
 	const v3 cam_o = o, cam_d = d;
@@ -1805,6 +1808,7 @@ static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t
 		alpha_ = ratio * fabs(gvi.e[2]);
 		if (K == ORC_BDPT_MAX) break; /* cap (not in the reference) */
 		alphas[K] = alpha; erec[K] = rec; eray_d[K] = d;
+		TR("eye %zu: p %.17g %.17g %.17g n %.6g %.6g %.6g poly %ld alpha %.9g alpha_ %.9g\n", K, rec.p.e[0], rec.p.e[1], rec.p.e[2], rec.normal.e[0], rec.normal.e[1], rec.normal.e[2], (long)rec.poly, alpha, alpha_);
 		double prr = 0.5;
 		K++;
 		if (K > 2) prr = 0.9;
@@ -1833,6 +1837,8 @@ static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t
 	double light_value = 0.0;
 	st->closest_rays++; /* :558 traces _ray (the eye subpath's last ray), not shadow_ray: same result as that ray's own trace */
 	if (last_eye_ray_hit) light_value = mat_emitted(mat_at(s, s->object_id[lf], last_eye_vt), b); /* Emitted(shadow_ray, sampled_light_rec, sampled_light_rec.vt) */
+	TR("pol %.17g %.17g %.17g dir %.17g %.17g %.17g\n", pol.e[0], pol.e[1], pol.e[2], dir.e[0], dir.e[1], dir.e[2]);
+	TR("K %zu last_hit %d light_value %.9g pol %.9g %.9g %.9g pdf_area %.9g dir_pdf_proj %.9g\n", K, last_eye_ray_hit, light_value, pol.e[0], pol.e[1], pol.e[2], light_pdf_area, light_dir_pdf_projected);
 	hitrec lrec[ORC_BDPT_MAX];
 	v3 lray_d[ORC_BDPT_MAX];
 	double betas[ORC_BDPT_MAX];
@@ -1854,6 +1860,7 @@ static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t
 		beta_ = ratio * fabs(gvi.e[2]);
 		if (L == ORC_BDPT_MAX) break; /* cap (not in the reference) */
 		betas[L] = beta; lrec[L] = rec; lray_d[L] = d;
+		TR("light %zu: p %.17g %.17g %.17g n %.6g %.6g %.6g poly %ld beta %.9g beta_ %.9g\n", L, rec.p.e[0], rec.p.e[1], rec.p.e[2], rec.normal.e[0], rec.normal.e[1], rec.normal.e[2], (long)rec.poly, beta, beta_);
 		double prr = 0.5;
 		L++;
 		if (L > 2) prr = 0.9;
@@ -1891,6 +1898,7 @@ static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t
 		if (!lm->light_flag) continue;
 		const double light = mat_emitted(lm, b);
 		radiances[total_length - 1] += alphas[e] * ratio * fabs(gvi.e[2]) * light;
+		TR("t0 e %zu: %.9g\n", e, alphas[e] * ratio * fabs(gvi.e[2]) * light);
 	}
 	for (size_t e = 0; e < K; e++) { /* s >= 1, t = 1, :692-716 */
 		size_t total_length = e + 2;
@@ -1904,6 +1912,7 @@ static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t
 		v3 vo = onb_w2l(&uvw, vneg(eray_d[e]));
 		double bsdf = mat_bsdf(rec_mat(s, &erec[e]), vi, b->central_wl, vo);
 		radiances[total_length - 1] += alphas[e] * bsdf * geometry_term(&erec[e], &light_rec) * mat_emitted(rec_mat(s, &light_rec), b) / light_pdf_area;
+		TR("t1 e %zu: bsdf %.9g G %.9g -> %.9g\n", e, bsdf, geometry_term(&erec[e], &light_rec), alphas[e] * bsdf * geometry_term(&erec[e], &light_rec) * mat_emitted(rec_mat(s, &light_rec), b) / light_pdf_area);
 	}
 	for (size_t e = 0; e < K; e++) { /* s >= 1, t > 1, :722-762 */
 		for (size_t l = 0; l < L; l++) {
@@ -1912,7 +1921,8 @@ static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t
 			v3 to = vsub(lrec[l].p, erec[e].p);
 			hitrec tmp;
 			st->shadow_rays++;
-			if (world_hit(s, WORLD_MODE, erec[e].p, vunit(to), 0.001, vlen(to) - 0.001, &tmp)) continue; /* Occluded = closest hit, hittable.h:34-40 */
+			TR("conn e %zu l %zu: len %.17g\n", e, l, vlen(to));
+			if (world_hit(s, WORLD_MODE, erec[e].p, vunit(to), 0.001, vlen(to) - 0.001, &tmp)) { TR("  occluded at t %.17g poly %ld\n", tmp.t, (long)tmp.poly); continue; } /* Occluded = closest hit, hittable.h:34-40 */
 			double eye_bsdf, light_bsdf;
 			{
 				onb uvw = onb_from_w(erec[e].normal);
@@ -1928,6 +1938,7 @@ static double naive_bdpt(const orc_scene *s, v3 o, v3 d, const band *b, uint64_t
 			}
 			radiances[total_length - 1] += alphas[e] * betas[l] * eye_bsdf * light_bsdf * geometry_term(&erec[e], &lrec[l]) * light_value /
 			                               (light_pdf_area * light_dir_pdf_projected);
+			TR("  eye_bsdf %.9g light_bsdf %.9g G %.9g -> %.9g\n", eye_bsdf, light_bsdf, geometry_term(&erec[e], &lrec[l]), alphas[e] * betas[l] * eye_bsdf * light_bsdf * geometry_term(&erec[e], &lrec[l]) * light_value / (light_pdf_area * light_dir_pdf_projected));
 		}
 	}
 	double radiance = 0.0;
@@ -1963,6 +1974,8 @@ void orc_render(const orc_scene *s, const orc_camera *cam, int nx, int ny, int n
 {
 	uint64_t closest = 0, shadow = 0, samples = 0;
 	set_threads(nthreads);
+	const char *trace_env = getenv("ORC_TRACE_PIXEL"); /* film index i * ny + j whose NaiveBDPT samples are written to stderr */
+	const long trace_pixel = trace_env ? atol(trace_env) : -1;
 	for (int smp = first_sample; smp < first_sample + n_samples; smp++) { /* renderer.cpp:69 */
 #pragma omp parallel for schedule(dynamic) reduction(+ : closest, shadow, samples)
 		for (int i = 0; i < nx; i++) {
@@ -1983,9 +1996,12 @@ void orc_render(const orc_scene *s, const orc_camera *cam, int nx, int ny, int n
 				double o[3], d[3], p_image, p_lens, cos_theta;
 				orc_camera_get_ray(cam, u, v, b.central_wl, lens, o, d, &p_image, &p_lens, &cos_theta);
 				orc_render_stats st = {0, 0, 0};
+				trace_on = trace_pixel == (long)i * ny + j;
 				double rad = radiance_dispatch(s, algorithm, vload(o), vload(d), &b, &rng, &st);
 				double geometry_factor = pow(cos_theta, 4.0) / (cam->d * cam->d); /* :113-114 */
+				TR("radiance %.9g\n", rad);
 				rad *= cam->film_sensitivity * geometry_factor / (p_image * p_lens);
+				TR("film value %.9g\n", rad);
 				if (!isnan(rad))
 					orc_spectrum_add(film + ((size_t)i * ny + j) * ORC_NBINS, rad / ns, b.min_wl, b.max_wl);
 				closest += st.closest_rays;
