@@ -312,7 +312,13 @@ __device__ __forceinline__ float spectrum_integrate(const float *data, const Dev
 __device__ __forceinline__ void film_add(float *film, uint32_t pixel, const DevBand &bd, float value) // spectrum.cpp:148-155
 {
 	if (isnan(value)) return; // renderer.cpp:115
+#if defined(EXP_FILM_STORE)
+	for (int i = bd.min_i; i <= bd.max_i; i++) film[(size_t)pixel * RT_NBINS + i] = value;
+#elif defined(EXP_FILM_NONE)
+	if (value == 12345.678f) film[pixel] = value;
+#else
 	for (int i = bd.min_i; i <= bd.max_i; i++) atomicAdd(&film[(size_t)pixel * RT_NBINS + i], value);
+#endif
 }
 
 // ---- per-hit material graphs: the Compute() chains of materialnode.cpp that read the hit's texture coordinate, compiled by the
